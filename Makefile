@@ -1,0 +1,32 @@
+# Builds the gfx950 shared library (the C ABI of include/myraytracer_amd.h), the headless
+# CLI, and the CPU oracle.  `python -c "import __graft_entry__ as g; g.build()"` runs this.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+CSRC     := myraytracer_amd/csrc
+LIBDIR   := myraytracer_amd/lib
+LIB      := $(LIBDIR)/libmyraytracer_amd.so
+CLI      := $(LIBDIR)/native_runner
+# -ffp-contract=off: fma only where the source says fma (MRT-F32 rules).
+# -fno-vectorize -fno-slp-vectorize: v_pk_* fp32 is not faster than scalar VALU on gfx950
+# and SLP packing spends s_mov on SGPR pairs (profiles/r01_ubench_sphere_loop_*.txt).
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-vectorize -fno-slp-vectorize -Wall -Wextra -Wno-unused-parameter
+SRCS     := $(CSRC)/kernels.hip $(CSRC)/api.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
+HDRS     := $(CSRC)/mrt_internal.h include/myraytracer_amd.h
+
+all: $(LIB) $(CLI) oracle
+
+$(LIB): $(SRCS) $(HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+
+$(CLI): $(CSRC)/native_runner.cpp $(LIB)
+	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/native_runner.cpp -L$(LIBDIR) -lmyraytracer_amd -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -s -C oracle
+
+clean:
+	rm -rf $(LIBDIR)
+	$(MAKE) -s -C oracle clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,239 @@
+/*
+ * myraytracer_amd.h -- C ABI of the MI355X-native backend for the per-pixel render loop
+ * of zetanumbers/myraytracer.
+ *
+ * The reference has no FFI / plugin seam for this path: the WGSL shader is
+ * include_str!-embedded (raytracer/src/lib.rs:1016) and run by a wgpu draw
+ * (lib.rs:262-267).  Each entry point below therefore names the reference item it
+ * replaces; INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add to
+ * raytracer/src/lib.rs to route `State` through this library.
+ *
+ * Conventions
+ *   - every function returns an mrt_status (0 = OK) unless stated; nothing aborts or
+ *     throws across the ABI (the reference panics via expect/unwrap, lib.rs:147,270,...).
+ *   - one mrt_ctx = one GPU = one caller thread at a time (the reference's State is
+ *     single-threaded and !Send, lib.rs:206-215).
+ *   - the caller owns every host array passed in (copied during the call) and every
+ *     output buffer; the ctx owns all device memory.
+ *   - framebuffer rows are bottom-up: row 0 is the BOTTOM of the picture
+ *     (shader.wgsl:26 vs sample_framebuffer.wgsl:24).
+ *   - all structs are plain C, 4-byte fields, no padding surprises (static_asserts in
+ *     csrc/api.cpp).
+ */
+#ifndef MYRAYTRACER_AMD_H
+#define MYRAYTRACER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRT_ABI_VERSION 1
+
+typedef enum {
+    MRT_OK = 0,
+    MRT_ERR_INVALID_ARG = 1,   /* null pointer, zero size, bad enum */
+    MRT_ERR_NO_DEVICE = 2,     /* no HIP device / wrong arch: the product never falls back to CPU */
+    MRT_ERR_HIP = 3,           /* a HIP runtime call failed; see mrt_last_error */
+    MRT_ERR_NO_SCENE = 4,      /* redraw before set_world */
+    MRT_ERR_BAD_SCENE = 5,     /* index out of range, non-finite or out-of-range geometry */
+    MRT_ERR_TOO_SMALL = 6,     /* caller buffer too small */
+    MRT_ERR_STATE = 7,         /* call not allowed in this state (e.g. reshard after first frame) */
+    MRT_ERR_IO = 8
+} mrt_status;
+
+/* ---- raytracer::Args, lib.rs:18-37; flags of native-runner/src/main.rs:20-31 ---- */
+typedef struct {
+    uint32_t width;                 /* default 0 */
+    uint32_t height;                /* default 0 */
+    uint32_t samples_per_frame;     /* default 1 */
+    uint32_t ray_depth;             /* default 50 */
+    float    max_framebuffer_weight;/* default 1.0 */
+} mrt_args;
+
+/* Args::default(), lib.rs:27-37 */
+void mrt_args_default(mrt_args* out);
+/* Size rule of App::resumed, lib.rs:113-134,149-154: both 0 -> default window size
+ * (MRT_DEFAULT_WIDTH x MRT_DEFAULT_HEIGHT here, there is no window); exactly one 0 ->
+ * square of the other. */
+#define MRT_DEFAULT_WIDTH 800
+#define MRT_DEFAULT_HEIGHT 600
+void mrt_args_resolve_size(mrt_args* inout);
+
+/* ---- Locals uniform, lib.rs:368-377 / shader.wgsl:8-17 (48 bytes) ---- */
+typedef struct {
+    uint32_t shape[2];
+    uint32_t samples_per_frame;
+    uint32_t ray_depth;
+    uint32_t rng_shuffle[4];
+    float    framebuffer_weight;
+    uint32_t _padding[3];
+} mrt_locals;
+
+/* ---- raw::World, lib.rs:641-685 / shader.wgsl:109-124,165-182 (64 bytes) plus the
+ *      Dielectric extension appended after MetalRange (80 bytes total) ---- */
+typedef struct {
+    int32_t center_base_idx, radius_base_idx, material_ty_base_idx, material_idx_base_idx;
+    int32_t length, _padding[3];
+} mrt_sphere_range;
+typedef struct { int32_t albedo_base_idx, length, _padding[2]; } mrt_lambertian_range;
+typedef struct { int32_t albedo_base_idx, fuzz_base_idx, length, _padding; } mrt_metal_range;
+typedef struct { int32_t ior_base_idx, length, _padding[2]; } mrt_dielectric_range;  /* extension */
+typedef struct {
+    mrt_sphere_range     spheres;
+    mrt_lambertian_range lambertians;
+    mrt_metal_range      metals;
+    mrt_dielectric_range dielectrics;
+} mrt_world;
+
+/* raw::MaterialTy, lib.rs:644-648 / shader.wgsl:126-127; 3 is the extension */
+enum { MRT_LAMBERTIAN = 1, MRT_METAL = 2, MRT_DIELECTRIC = 3 };
+
+/* ---- api::Sphere / api::DynMaterial, lib.rs:611-639, flattened to one POD ----
+ * albedo is used by Lambertian and Metal; param = fuzz (Metal) or index of refraction
+ * (Dielectric). 36 bytes. */
+typedef struct {
+    float   center[3];
+    float   radius;
+    int32_t material_ty;
+    float   albedo[3];
+    float   param;
+} mrt_sphere;
+
+/* ---- camera (extension; mode 0 is the reference's fixed pinhole, shader.wgsl:360-381) */
+typedef struct {
+    int32_t mode;                  /* 0 = reference pinhole, 1 = look-at thin lens */
+    float   lookfrom[3], lookat[3], vup[3];
+    float   vfov_deg, defocus_angle_deg, focus_dist;
+} mrt_camera;
+typedef struct {                   /* what the kernel consumes; derived on the host in double */
+    int32_t mode, defocus;
+    float   origin[3], su[3], sv[3], fw[3], ru[3], rv[3];
+} mrt_camera_raw;
+
+typedef struct {
+    uint64_t samples;              /* camera rays started */
+    uint64_t world_hit_calls;      /* = bounces; sphere tests = world_hit_calls * spheres.length */
+    uint64_t rng_draws;            /* xoshiro128+ outputs consumed */
+} mrt_counters;
+
+typedef struct mrt_ctx mrt_ctx;
+
+/* ------------------------------------------------------------------ lifecycle */
+
+/* App::new + State::new (lib.rs:77,217-234): allocates the seed texture (Subject::new,
+ * lib.rs:389-415; seeded deterministically from `seed` instead of entropy), the two
+ * ping-pong framebuffers (DoubleFramebuffers::new, lib.rs:514-538) and the Locals.
+ * `device` is the HIP device ordinal.  Fails with MRT_ERR_NO_DEVICE if there is none. */
+int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out);
+/* Drop of State's wgpu handles */
+void mrt_destroy(mrt_ctx* ctx);
+
+/* Tile sharding for multi-GPU (no reference counterpart): this ctx renders the 8-row
+ * bands b with b % world == rank.  Must be called before the first redraw.  Seeds are
+ * keyed by global pixel index, so any sharding yields the same image. */
+int mrt_set_shard(mrt_ctx* ctx, uint32_t rank, uint32_t world);
+/* hipStream_t to launch on (e.g. torch's current stream); NULL = the ctx's own stream. */
+int mrt_set_stream(mrt_ctx* ctx, void* hip_stream);
+
+/* ------------------------------------------------------------------ scene */
+
+/* Object::new's upload (lib.rs:768-863): the raw::World index block and the three SoA
+ * arrays, verbatim.  vec4_data: n_vec4 x 4 floats, f32_data: n_f32 floats, i32_data:
+ * n_i32 ints.  All base+length ranges are validated. */
+int mrt_set_world_raw(mrt_ctx* ctx, const mrt_world* world,
+                      const float* vec4_data, size_t n_vec4,
+                      const float* f32_data, size_t n_f32,
+                      const int32_t* i32_data, size_t n_i32);
+/* api::World { spheres } (lib.rs:611-639) -> packs with mrt_pack_world, then uploads */
+int mrt_set_world(mrt_ctx* ctx, const mrt_sphere* spheres, size_t n);
+/* The AoS -> SoA packing of lib.rs:722-799 (host only, no GPU needed).  Capacities are
+ * in elements (vec4: 4 floats each); returns MRT_ERR_TOO_SMALL if any is short.
+ * Needs at most 2n vec4, 2n f32, 2n i32. */
+int mrt_pack_world(const mrt_sphere* spheres, size_t n, mrt_world* world,
+                   float* vec4_data, size_t cap_vec4, size_t* n_vec4,
+                   float* f32_data, size_t cap_f32, size_t* n_f32,
+                   int32_t* i32_data, size_t cap_i32, size_t* n_i32);
+
+int mrt_set_camera(mrt_ctx* ctx, const mrt_camera* cam);
+int mrt_camera_derive(const mrt_camera* cam, mrt_camera_raw* out);   /* host only */
+
+/* Replace the seed texture (Rgba32Uint W x H of lib.rs:397-415): seeds = W*H*4 u32,
+ * row 0 = bottom.  Optional: mrt_create already fills it from `seed`. */
+int mrt_set_seeds(mrt_ctx* ctx, const uint32_t* seeds, size_t n_u32);
+int mrt_read_seeds(mrt_ctx* ctx, uint32_t* out, size_t cap_u32);    /* this shard's rows, packed */
+
+/* ------------------------------------------------------------------ frame loop */
+
+/* State::redraw (lib.rs:241-307) minus the present pass: one raytrace pass of
+ * samples_per_frame spp into framebuffers.target blended with .secondary, swap,
+ * sample_count += 1, framebuffer_weight = min(max_w, n/(n+1)), new rng_shuffle, Locals
+ * update.  Asynchronous on the ctx's stream. */
+int mrt_redraw(mrt_ctx* ctx);
+/* `frames` x mrt_redraw */
+int mrt_render(mrt_ctx* ctx, uint32_t frames);
+int mrt_sync(mrt_ctx* ctx);
+/* Restart accumulation: zero framebuffers, frame counter 0, weight 0, shuffle [0;4]. */
+int mrt_reset(mrt_ctx* ctx);
+
+/* Current Locals (what the NEXT redraw will use) */
+int mrt_get_locals(mrt_ctx* ctx, mrt_locals* out);
+/* Override the next frame's rng_shuffle (the reference draws it from thread_rng, lib.rs:305) */
+int mrt_set_rng_shuffle(mrt_ctx* ctx, const uint32_t shuffle[4]);
+int mrt_set_samples_per_frame(mrt_ctx* ctx, uint32_t spp);
+uint32_t mrt_frames_done(mrt_ctx* ctx);
+
+/* host-only helpers exposing the schedule of lib.rs:300-305 */
+float mrt_frame_weight(uint32_t frames_done, float max_framebuffer_weight);
+void  mrt_frame_shuffle(uint64_t seed, uint32_t frame, uint32_t out[4]);
+void  mrt_pixel_seed(uint64_t seed, uint64_t pixel_index, uint32_t out[4]);
+
+/* ------------------------------------------------------------------ output */
+
+/* Geometry of this shard's packed framebuffer: local_rows rows of `width` RGBA f32
+ * texels; local row r is global row ((r/8)*world + rank)*8 + r%8 (rows >= height are
+ * padding and hold zeros). */
+int mrt_shard_info(mrt_ctx* ctx, uint32_t* rank, uint32_t* world, uint32_t* local_rows, uint32_t* width);
+/* Device pointer of the most recently rendered framebuffer (local_rows*width*4 floats),
+ * for zero-copy hand-off to RCCL / torch.  Valid until the next redraw/destroy. */
+void* mrt_framebuffer_device_ptr(mrt_ctx* ctx);
+/* Read-back (no reference counterpart; the reference only presents, lib.rs:270-297).
+ * world == 1: the full image, height*width*4 floats, row 0 = bottom.
+ * world  > 1: this shard's packed rows, local_rows*width*4 floats. */
+int mrt_read_framebuffer(mrt_ctx* ctx, float* rgba_out, size_t cap_floats);
+int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since create/reset */
+/* Elapsed GPU time (ms) of the most recent redraw's render kernel, from HIP events on
+ * the launch stream.  Synchronises on the stop event. */
+int mrt_last_kernel_ms(mrt_ctx* ctx, float* ms);
+
+const char* mrt_last_error(mrt_ctx* ctx);       /* never NULL; ctx may be NULL */
+const char* mrt_status_string(int status);
+int mrt_abi_version(void);
+
+/* ------------------------------------------------------------------ scenes (host only) */
+
+/* The shipped 4-sphere scene, lib.rs:687-720.  Returns the sphere count (4) or a
+ * negative mrt_status; writes min(cap, n) spheres. */
+int mrt_scene_default(mrt_sphere* out, size_t cap);
+/* RTIOW cover scene (extension): ground + 22x22 grid + 3 big spheres.
+ * dielectric == 0 emits glass slots as Metal(0.9,0.9,0.9; fuzz 0) (config C2),
+ * dielectric != 0 as Dielectric(1.5) (C3/C4).  cam_out (optional) gets the matching
+ * camera (defocus only when dielectric != 0). */
+int mrt_scene_cover(uint64_t scene_seed, int dielectric, mrt_sphere* out, size_t cap, mrt_camera* cam_out);
+/* 10k-sphere stress scene (C5): ground + n_side x n_side jittered grid, 80/15/5 % L/M/D */
+int mrt_scene_stress(uint64_t scene_seed, uint32_t n_side, mrt_sphere* out, size_t cap, mrt_camera* cam_out);
+
+/* ------------------------------------------------------------------ image output (host only) */
+
+/* rgba: height*width*4 floats, row 0 = bottom (as read back).  PFM keeps linear floats
+ * (bottom-up is PFM's native order); PPM applies gamma 2.0 (sqrt) and flips to top-down,
+ * which is what the reference's present pass + sRGB surface approximates on screen. */
+int mrt_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height);
+int mrt_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYRAYTRACER_AMD_H */

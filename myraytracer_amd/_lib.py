@@ -1,0 +1,141 @@
+"""ctypes binding of the C ABI declared in include/myraytracer_amd.h.
+
+The shared library is built in-tree (myraytracer_amd/lib/libmyraytracer_amd.so, see the
+top-level Makefile).  There is no fallback of any kind: a missing library raises
+ImportError, a missing GPU makes mrt_create fail with MRT_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmyraytracer_amd.so")
+
+# every symbol include/myraytracer_amd.h declares (tests/test_abi.py checks this list
+# against the header and against the loaded library)
+EXPORTS = [
+    "mrt_args_default", "mrt_args_resolve_size", "mrt_create", "mrt_destroy", "mrt_set_shard",
+    "mrt_set_stream", "mrt_set_world_raw", "mrt_set_world", "mrt_pack_world", "mrt_set_camera",
+    "mrt_camera_derive", "mrt_set_seeds", "mrt_read_seeds", "mrt_redraw", "mrt_render", "mrt_sync",
+    "mrt_reset", "mrt_get_locals", "mrt_set_rng_shuffle", "mrt_set_samples_per_frame",
+    "mrt_frames_done", "mrt_frame_weight", "mrt_frame_shuffle", "mrt_pixel_seed", "mrt_shard_info",
+    "mrt_framebuffer_device_ptr", "mrt_read_framebuffer", "mrt_read_counters", "mrt_last_kernel_ms",
+    "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_scene_default", "mrt_scene_cover",
+    "mrt_scene_stress", "mrt_write_pfm", "mrt_write_ppm",
+]
+
+
+class MrtArgs(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples_per_frame", C.c_uint32),
+                ("ray_depth", C.c_uint32), ("max_framebuffer_weight", C.c_float)]
+
+
+class MrtLocals(C.Structure):
+    _fields_ = [("shape", C.c_uint32 * 2), ("samples_per_frame", C.c_uint32), ("ray_depth", C.c_uint32),
+                ("rng_shuffle", C.c_uint32 * 4), ("framebuffer_weight", C.c_float), ("_padding", C.c_uint32 * 3)]
+
+
+class MrtSphereRange(C.Structure):
+    _fields_ = [("center_base_idx", C.c_int32), ("radius_base_idx", C.c_int32),
+                ("material_ty_base_idx", C.c_int32), ("material_idx_base_idx", C.c_int32),
+                ("length", C.c_int32), ("_padding", C.c_int32 * 3)]
+
+
+class MrtLambertianRange(C.Structure):
+    _fields_ = [("albedo_base_idx", C.c_int32), ("length", C.c_int32), ("_padding", C.c_int32 * 2)]
+
+
+class MrtMetalRange(C.Structure):
+    _fields_ = [("albedo_base_idx", C.c_int32), ("fuzz_base_idx", C.c_int32), ("length", C.c_int32),
+                ("_padding", C.c_int32)]
+
+
+class MrtDielectricRange(C.Structure):
+    _fields_ = [("ior_base_idx", C.c_int32), ("length", C.c_int32), ("_padding", C.c_int32 * 2)]
+
+
+class MrtWorld(C.Structure):
+    _fields_ = [("spheres", MrtSphereRange), ("lambertians", MrtLambertianRange),
+                ("metals", MrtMetalRange), ("dielectrics", MrtDielectricRange)]
+
+
+class MrtSphere(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("material_ty", C.c_int32),
+                ("albedo", C.c_float * 3), ("param", C.c_float)]
+
+
+class MrtCamera(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("lookfrom", C.c_float * 3), ("lookat", C.c_float * 3),
+                ("vup", C.c_float * 3), ("vfov_deg", C.c_float), ("defocus_angle_deg", C.c_float),
+                ("focus_dist", C.c_float)]
+
+
+class MrtCameraRaw(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("defocus", C.c_int32), ("origin", C.c_float * 3), ("su", C.c_float * 3),
+                ("sv", C.c_float * 3), ("fw", C.c_float * 3), ("ru", C.c_float * 3), ("rv", C.c_float * 3)]
+
+
+class MrtCounters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("world_hit_calls", C.c_uint64), ("rng_draws", C.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    """Load the in-tree shared library (once) and declare the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make` at the repo root "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "myraytracer_amd has no Python or CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32, f32, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float, C.c_size_t
+    P = C.POINTER
+    sig = {
+        "mrt_args_default": (None, [P(MrtArgs)]),
+        "mrt_args_resolve_size": (None, [P(MrtArgs)]),
+        "mrt_create": (i32, [P(MrtArgs), u64, i32, P(vp)]),
+        "mrt_destroy": (None, [vp]),
+        "mrt_set_shard": (i32, [vp, u32, u32]),
+        "mrt_set_stream": (i32, [vp, vp]),
+        "mrt_set_world_raw": (i32, [vp, P(MrtWorld), vp, sz, vp, sz, vp, sz]),
+        "mrt_set_world": (i32, [vp, vp, sz]),
+        "mrt_pack_world": (i32, [vp, sz, P(MrtWorld), vp, sz, P(sz), vp, sz, P(sz), vp, sz, P(sz)]),
+        "mrt_set_camera": (i32, [vp, P(MrtCamera)]),
+        "mrt_camera_derive": (i32, [P(MrtCamera), P(MrtCameraRaw)]),
+        "mrt_set_seeds": (i32, [vp, vp, sz]),
+        "mrt_read_seeds": (i32, [vp, vp, sz]),
+        "mrt_redraw": (i32, [vp]),
+        "mrt_render": (i32, [vp, u32]),
+        "mrt_sync": (i32, [vp]),
+        "mrt_reset": (i32, [vp]),
+        "mrt_get_locals": (i32, [vp, P(MrtLocals)]),
+        "mrt_set_rng_shuffle": (i32, [vp, P(u32)]),
+        "mrt_set_samples_per_frame": (i32, [vp, u32]),
+        "mrt_frames_done": (u32, [vp]),
+        "mrt_frame_weight": (f32, [u32, f32]),
+        "mrt_frame_shuffle": (None, [u64, u32, P(u32)]),
+        "mrt_pixel_seed": (None, [u64, u64, P(u32)]),
+        "mrt_shard_info": (i32, [vp, P(u32), P(u32), P(u32), P(u32)]),
+        "mrt_framebuffer_device_ptr": (vp, [vp]),
+        "mrt_read_framebuffer": (i32, [vp, vp, sz]),
+        "mrt_read_counters": (i32, [vp, P(MrtCounters)]),
+        "mrt_last_kernel_ms": (i32, [vp, P(f32)]),
+        "mrt_last_error": (C.c_char_p, [vp]),
+        "mrt_status_string": (C.c_char_p, [i32]),
+        "mrt_abi_version": (i32, []),
+        "mrt_scene_default": (i32, [vp, sz]),
+        "mrt_scene_cover": (i32, [u64, i32, vp, sz, P(MrtCamera)]),
+        "mrt_scene_stress": (i32, [u64, u32, vp, sz, P(MrtCamera)]),
+        "mrt_write_pfm": (i32, [C.c_char_p, vp, u32, u32]),
+        "mrt_write_ppm": (i32, [C.c_char_p, vp, u32, u32]),
+    }
+    assert sorted(sig) == sorted(EXPORTS)
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here = the .so does not export the header's symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L

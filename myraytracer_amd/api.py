@@ -1,0 +1,320 @@
+"""Host-side mirror of the reference's interface for the render path, over the C ABI.
+
+Names follow raytracer/src/lib.rs: `Args` (lib.rs:18-37), the scene description
+`Lambertian` / `Metal` / `Sphere` / `World` (the fn-local `api` module, lib.rs:611-639;
+`Dielectric` is the extension), and `State` with `redraw()` (lib.rs:206-308).  The
+reference's toolchain (Rust) is not in this image, so this mirror is Python over ctypes;
+INTEGRATION.md shows the Rust binding of the same ABI.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import MrtArgs, MrtCamera, MrtCameraRaw, MrtCounters, MrtLocals, MrtSphere, MrtWorld
+
+LAMBERTIAN, METAL, DIELECTRIC = 1, 2, 3          # raw::MaterialTy, lib.rs:644-648 (+ extension)
+SPHERE_DTYPE = np.dtype([("center", "<f4", 3), ("radius", "<f4"), ("material_ty", "<i4"),
+                         ("albedo", "<f4", 3), ("param", "<f4")])
+assert SPHERE_DTYPE.itemsize == C.sizeof(MrtSphere) == 36
+
+
+class MrtError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        name = _lib.load().mrt_status_string(status).decode()
+        super().__init__(f"{where}: {name}" + (f" ({detail})" if detail else ""))
+
+
+@dataclass
+class Args:
+    """raytracer::Args (lib.rs:18-37), same defaults."""
+    width: int = 0
+    height: int = 0
+    samples_per_frame: int = 1
+    ray_depth: int = 50
+    max_framebuffer_weight: float = 1.0
+
+    def resolved(self) -> "Args":
+        """The size rule of App::resumed (lib.rs:113-134)."""
+        a = MrtArgs(self.width, self.height, self.samples_per_frame, self.ray_depth, self.max_framebuffer_weight)
+        _lib.load().mrt_args_resolve_size(C.byref(a))
+        return Args(a.width, a.height, a.samples_per_frame, a.ray_depth, a.max_framebuffer_weight)
+
+    def _c(self) -> MrtArgs:
+        return MrtArgs(self.width, self.height, self.samples_per_frame, self.ray_depth, self.max_framebuffer_weight)
+
+
+@dataclass
+class Lambertian:          # api::Lambertian, lib.rs:613-616
+    albedo: Tuple[float, float, float]
+
+
+@dataclass
+class Metal:               # api::Metal, lib.rs:618-622
+    albedo: Tuple[float, float, float]
+    fuzz: float
+
+
+@dataclass
+class Dielectric:          # extension (material type 3)
+    ior: float
+
+
+@dataclass
+class Sphere:              # api::Sphere, lib.rs:630-635
+    center: Tuple[float, float, float]
+    radius: float
+    material: object
+
+
+@dataclass
+class World:               # api::World, lib.rs:637-639
+    spheres: List[Sphere] = field(default_factory=list)
+
+    def to_array(self) -> np.ndarray:
+        out = np.zeros(len(self.spheres), SPHERE_DTYPE)
+        for i, s in enumerate(self.spheres):
+            m = s.material
+            if isinstance(m, Lambertian):
+                out[i] = (s.center, s.radius, LAMBERTIAN, m.albedo, 0.0)
+            elif isinstance(m, Metal):
+                out[i] = (s.center, s.radius, METAL, m.albedo, m.fuzz)
+            elif isinstance(m, Dielectric):
+                out[i] = (s.center, s.radius, DIELECTRIC, (1.0, 1.0, 1.0), m.ior)
+            else:
+                raise TypeError(f"unknown material {m!r}")
+        return out
+
+
+@dataclass
+class Camera:
+    """mode 0 = the reference's fixed pinhole (shader.wgsl:360-381); mode 1 = look-at thin lens."""
+    mode: int = 0
+    lookfrom: Sequence[float] = (0.0, 0.0, 0.0)
+    lookat: Sequence[float] = (0.0, 0.0, -1.0)
+    vup: Sequence[float] = (0.0, 1.0, 0.0)
+    vfov_deg: float = 90.0
+    defocus_angle_deg: float = 0.0
+    focus_dist: float = 1.0
+
+    def _c(self) -> MrtCamera:
+        c = MrtCamera()
+        c.mode = self.mode
+        c.lookfrom[:] = list(self.lookfrom)
+        c.lookat[:] = list(self.lookat)
+        c.vup[:] = list(self.vup)
+        c.vfov_deg, c.defocus_angle_deg, c.focus_dist = self.vfov_deg, self.defocus_angle_deg, self.focus_dist
+        return c
+
+    @staticmethod
+    def _from_c(c: MrtCamera) -> "Camera":
+        return Camera(c.mode, tuple(c.lookfrom), tuple(c.lookat), tuple(c.vup), c.vfov_deg,
+                      c.defocus_angle_deg, c.focus_dist)
+
+
+# ------------------------------------------------------------------ host-only helpers
+
+def pack_world(spheres: np.ndarray):
+    """lib.rs:722-799 through mrt_pack_world -> (MrtWorld, vec4[n,4], f32[n], i32[n])."""
+    L = _lib.load()
+    spheres = np.ascontiguousarray(spheres, SPHERE_DTYPE)
+    n = len(spheres)
+    vec4 = np.zeros((2 * n + 1, 4), np.float32)
+    f32 = np.zeros(2 * n + 1, np.float32)
+    i32 = np.zeros(2 * n + 1, np.int32)
+    w = MrtWorld()
+    nv, nf, ni = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    st = L.mrt_pack_world(spheres.ctypes.data, n, C.byref(w), vec4.ctypes.data, 2 * n + 1, C.byref(nv),
+                          f32.ctypes.data, 2 * n + 1, C.byref(nf), i32.ctypes.data, 2 * n + 1, C.byref(ni))
+    if st:
+        raise MrtError(st, "mrt_pack_world")
+    return w, vec4[:nv.value].copy(), f32[:nf.value].copy(), i32[:ni.value].copy()
+
+
+def camera_derive(cam: Camera) -> MrtCameraRaw:
+    raw = MrtCameraRaw()
+    st = _lib.load().mrt_camera_derive(C.byref(cam._c()), C.byref(raw))
+    if st:
+        raise MrtError(st, "mrt_camera_derive")
+    return raw
+
+
+def frame_weight(frames_done: int, max_w: float) -> float:
+    return float(_lib.load().mrt_frame_weight(frames_done, max_w))
+
+
+def frame_shuffle(seed: int, frame: int) -> List[int]:
+    out = (C.c_uint32 * 4)()
+    _lib.load().mrt_frame_shuffle(seed, frame, out)
+    return [int(x) for x in out]
+
+
+def pixel_seed(seed: int, pixel_index: int) -> List[int]:
+    out = (C.c_uint32 * 4)()
+    _lib.load().mrt_pixel_seed(seed, pixel_index, out)
+    return [int(x) for x in out]
+
+
+def scene_default() -> np.ndarray:
+    """The shipped 4-sphere scene (lib.rs:687-720)."""
+    out = np.zeros(4, SPHERE_DTYPE)
+    n = _lib.load().mrt_scene_default(out.ctypes.data, 4)
+    assert n == 4
+    return out
+
+
+def scene_cover(scene_seed: int = 1, dielectric: bool = False):
+    out = np.zeros(512, SPHERE_DTYPE)
+    cam = MrtCamera()
+    n = _lib.load().mrt_scene_cover(scene_seed, int(dielectric), out.ctypes.data, len(out), C.byref(cam))
+    if n < 0 or n > len(out):
+        raise MrtError(-n if n < 0 else 6, "mrt_scene_cover")
+    return out[:n].copy(), Camera._from_c(cam)
+
+
+def scene_stress(scene_seed: int = 1, n_side: int = 100):
+    out = np.zeros(n_side * n_side + 1, SPHERE_DTYPE)
+    cam = MrtCamera()
+    n = _lib.load().mrt_scene_stress(scene_seed, n_side, out.ctypes.data, len(out), C.byref(cam))
+    if n < 0 or n > len(out):
+        raise MrtError(-n if n < 0 else 6, "mrt_scene_stress")
+    return out[:n].copy(), Camera._from_c(cam)
+
+
+def write_image(path: str, rgba: np.ndarray):
+    """rgba: (H, W, 4) f32, row 0 = bottom.  .ppm -> 8-bit gamma-2, anything else -> PFM."""
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w, _ = rgba.shape
+    fn = _lib.load().mrt_write_ppm if path.endswith(".ppm") else _lib.load().mrt_write_pfm
+    st = fn(path.encode(), rgba.ctypes.data, w, h)
+    if st:
+        raise MrtError(st, "write_image", path)
+
+
+# ------------------------------------------------------------------ State
+
+class State:
+    """The in-scope part of raytracer's `State` (lib.rs:206-308) on one MI355X.
+
+    State(args, seed) ~ State::new; set_world ~ Object::new's upload; redraw() ~
+    State::redraw (raytrace pass + swap + weight/shuffle update).
+    """
+
+    def __init__(self, args: Args, seed: int = 1, device: int = 0, shard: Optional[Tuple[int, int]] = None,
+                 stream: Optional[int] = None):
+        self._L = _lib.load()
+        self._ctx = C.c_void_p()
+        self.args = args.resolved()
+        st = self._L.mrt_create(C.byref(args._c()), seed, device, C.byref(self._ctx))
+        if st:
+            raise MrtError(st, "mrt_create", self._L.mrt_last_error(None).decode())
+        if shard is not None:
+            self._check(self._L.mrt_set_shard(self._ctx, shard[0], shard[1]), "mrt_set_shard")
+        if stream is not None:
+            self._check(self._L.mrt_set_stream(self._ctx, stream), "mrt_set_stream")
+
+    def _check(self, st, where):
+        if st:
+            raise MrtError(st, where, self._L.mrt_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.mrt_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene
+    def set_world(self, world):
+        arr = world.to_array() if isinstance(world, World) else np.ascontiguousarray(world, SPHERE_DTYPE)
+        self._check(self._L.mrt_set_world(self._ctx, arr.ctypes.data, len(arr)), "mrt_set_world")
+
+    def set_world_raw(self, w: MrtWorld, vec4: np.ndarray, f32: np.ndarray, i32: np.ndarray):
+        vec4 = np.ascontiguousarray(vec4, np.float32).reshape(-1, 4)
+        f32 = np.ascontiguousarray(f32, np.float32)
+        i32 = np.ascontiguousarray(i32, np.int32)
+        self._check(self._L.mrt_set_world_raw(self._ctx, C.byref(w), vec4.ctypes.data, len(vec4), f32.ctypes.data,
+                                              len(f32), i32.ctypes.data, len(i32)), "mrt_set_world_raw")
+
+    def set_camera(self, cam: Camera):
+        self._check(self._L.mrt_set_camera(self._ctx, C.byref(cam._c())), "mrt_set_camera")
+
+    def set_seeds(self, seeds: np.ndarray):
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        self._check(self._L.mrt_set_seeds(self._ctx, seeds.ctypes.data, seeds.size), "mrt_set_seeds")
+
+    def read_seeds(self) -> np.ndarray:
+        rows, w = self.shard_info()[2:]
+        out = np.empty((rows, w, 4), np.uint32)
+        self._check(self._L.mrt_read_seeds(self._ctx, out.ctypes.data, out.size), "mrt_read_seeds")
+        return out
+
+    # -- frame loop
+    def redraw(self):
+        self._check(self._L.mrt_redraw(self._ctx), "mrt_redraw")
+
+    def render(self, frames: int = 1):
+        self._check(self._L.mrt_render(self._ctx, frames), "mrt_render")
+
+    def sync(self):
+        self._check(self._L.mrt_sync(self._ctx), "mrt_sync")
+
+    def reset(self):
+        self._check(self._L.mrt_reset(self._ctx), "mrt_reset")
+
+    @property
+    def locals(self) -> MrtLocals:
+        out = MrtLocals()
+        self._check(self._L.mrt_get_locals(self._ctx, C.byref(out)), "mrt_get_locals")
+        return out
+
+    def set_rng_shuffle(self, shuffle: Sequence[int]):
+        self._check(self._L.mrt_set_rng_shuffle(self._ctx, (C.c_uint32 * 4)(*shuffle)), "mrt_set_rng_shuffle")
+
+    def set_samples_per_frame(self, spp: int):
+        self._check(self._L.mrt_set_samples_per_frame(self._ctx, spp), "mrt_set_samples_per_frame")
+
+    @property
+    def frames_done(self) -> int:
+        return int(self._L.mrt_frames_done(self._ctx))
+
+    # -- output
+    def shard_info(self) -> Tuple[int, int, int, int]:
+        r, w, rows, width = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self._L.mrt_shard_info(self._ctx, C.byref(r), C.byref(w), C.byref(rows), C.byref(width)),
+                    "mrt_shard_info")
+        return r.value, w.value, rows.value, width.value
+
+    def framebuffer_device_ptr(self) -> int:
+        return int(self._L.mrt_framebuffer_device_ptr(self._ctx) or 0)
+
+    def read_framebuffer(self) -> np.ndarray:
+        """(H, W, 4) f32, row 0 = bottom (world == 1) or this shard's packed (local_rows, W, 4)."""
+        _, world, rows, width = self.shard_info()
+        shape = (self.args.height, width, 4) if world == 1 else (rows, width, 4)
+        out = np.empty(shape, np.float32)
+        self._check(self._L.mrt_read_framebuffer(self._ctx, out.ctypes.data, out.size), "mrt_read_framebuffer")
+        return out
+
+    def read_counters(self) -> dict:
+        c = MrtCounters()
+        self._check(self._L.mrt_read_counters(self._ctx, C.byref(c)), "mrt_read_counters")
+        return {"samples": int(c.samples), "world_hit_calls": int(c.world_hit_calls), "rng_draws": int(c.rng_draws)}
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self._L.mrt_last_kernel_ms(self._ctx, C.byref(ms)), "mrt_last_kernel_ms")
+        return float(ms.value)

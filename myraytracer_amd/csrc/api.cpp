@@ -1,0 +1,604 @@
+// Host side of the C ABI (include/myraytracer_amd.h): the in-scope parts of the
+// reference's `State` (raytracer/src/lib.rs:206-308) -- Subject (Locals + seed texture),
+// Object (scene packing + upload), DoubleFramebuffers (ping-pong accumulators) and the
+// tail of State::redraw (accumulation weights, reshuffle) -- over HIP allocations and one
+// kernel launch per frame instead of wgpu bind groups and a full-screen draw.
+//
+// There is deliberately no CPU fallback: without a gfx950 device mrt_create fails with
+// MRT_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mrt_internal.h"
+
+static_assert(sizeof(mrt_args) == 20, "mrt_args layout");
+static_assert(sizeof(mrt_locals) == 48, "Locals is 48 bytes (lib.rs:368-377)");
+static_assert(sizeof(mrt_world) == 80, "raw::World 64 B + DielectricRange 16 B");
+static_assert(sizeof(mrt_sphere) == 36, "mrt_sphere layout");
+static_assert(sizeof(mrt_camera) == 52, "mrt_camera layout");
+static_assert(sizeof(mrt_camera_raw) == 80, "mrt_camera_raw layout");
+static_assert(sizeof(mrt::SphereRec) == 16, "SphereRec layout");
+
+struct mrt_ctx {
+    int device = 0;
+    mrt_args args{};
+    uint64_t seed = 0;
+    mrt_locals locals{};
+    uint32_t frames_done = 0;          // State::sample_count (lib.rs:213, 300)
+    bool shuffle_overridden = false;
+
+    uint32_t shard_rank = 0, shard_world = 1;
+    uint32_t local_bands = 0;
+
+    mrt_world world{};
+    bool have_world = false;
+    uint32_t n_spheres = 0, n_padded = 0;
+    mrt_camera camera{};
+    mrt_camera_raw cam_raw{};
+
+    // device memory (all owned)
+    mrt::SphereRec* d_spheres = nullptr;
+    float* d_vec4 = nullptr;
+    float* d_f32 = nullptr;
+    int32_t* d_i32 = nullptr;
+    uint32_t* d_seeds = nullptr;
+    float* d_fb[2] = {nullptr, nullptr};   // [target, secondary] ping-pong (lib.rs:505-543)
+    int target = 0;                        // index of the buffer the NEXT redraw writes
+    unsigned long long* d_counters = nullptr;
+
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err;   // for failures before a ctx exists
+
+int fail(mrt_ctx* ctx, int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_err = buf;
+    return status;
+}
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, MRT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+uint32_t total_bands(uint32_t height) { return (height + mrt::kBandRows - 1) / mrt::kBandRows; }
+
+size_t local_texels(const mrt_ctx* c) { return (size_t)c->local_bands * mrt::kBandRows * c->args.width; }
+
+void free_frame_buffers(mrt_ctx* c) {
+    if (c->d_seeds) (void)hipFree(c->d_seeds);
+    if (c->d_fb[0]) (void)hipFree(c->d_fb[0]);
+    if (c->d_fb[1]) (void)hipFree(c->d_fb[1]);
+    c->d_seeds = nullptr; c->d_fb[0] = c->d_fb[1] = nullptr;
+}
+
+void free_world(mrt_ctx* c) {
+    if (c->d_spheres) (void)hipFree(c->d_spheres);
+    if (c->d_vec4) (void)hipFree(c->d_vec4);
+    if (c->d_f32) (void)hipFree(c->d_f32);
+    if (c->d_i32) (void)hipFree(c->d_i32);
+    c->d_spheres = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
+    c->have_world = false;
+}
+
+// Subject::new + DoubleFramebuffers::new for the current shard (lib.rs:389-415, 514-538)
+int alloc_frame_buffers(mrt_ctx* c) {
+    free_frame_buffers(c);
+    const uint32_t nb = total_bands(c->args.height);
+    c->local_bands = (nb + c->shard_world - 1) / c->shard_world;   // same on every rank (gather-friendly)
+    const size_t n = local_texels(c);
+    HIP_TRY(c, hipMalloc(&c->d_seeds, n * 4 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_fb[0], n * 4 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->d_fb[1], n * 4 * sizeof(float)));
+    HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, n * 4 * sizeof(float), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, n * 4 * sizeof(float), c->stream));
+    int e = mrt::launch_fill_seeds(c->d_seeds, c->seed, c->args.width, c->args.height, c->shard_rank,
+                                   c->shard_world, c->local_bands, c->stream);
+    if (e) return fail(c, MRT_ERR_HIP, "fill_seeds launch failed: %s", hipGetErrorString((hipError_t)e));
+    c->target = 0;
+    return MRT_OK;
+}
+
+void reset_locals(mrt_ctx* c) {
+    // lib.rs:419-426: initial Locals
+    std::memset(&c->locals, 0, sizeof c->locals);
+    c->locals.shape[0] = c->args.width;
+    c->locals.shape[1] = c->args.height;
+    c->locals.samples_per_frame = c->args.samples_per_frame;
+    c->locals.ray_depth = c->args.ray_depth;
+    c->locals.framebuffer_weight = 0.0f;
+    c->frames_done = 0;
+    c->shuffle_overridden = false;
+}
+
+uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1u) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+bool finite_in_range(float v, float lim) { return std::isfinite(v) && std::fabs(v) <= lim; }
+
+}  // namespace
+
+extern "C" {
+
+int mrt_abi_version(void) { return MRT_ABI_VERSION; }
+
+const char* mrt_status_string(int s) {
+    switch (s) {
+        case MRT_OK: return "ok";
+        case MRT_ERR_INVALID_ARG: return "invalid argument";
+        case MRT_ERR_NO_DEVICE: return "no usable HIP device";
+        case MRT_ERR_HIP: return "HIP runtime error";
+        case MRT_ERR_NO_SCENE: return "no scene set";
+        case MRT_ERR_BAD_SCENE: return "invalid scene data";
+        case MRT_ERR_TOO_SMALL: return "buffer too small";
+        case MRT_ERR_STATE: return "call not allowed in this state";
+        case MRT_ERR_IO: return "i/o error";
+        default: return "unknown status";
+    }
+}
+
+const char* mrt_last_error(mrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+void mrt_args_default(mrt_args* out) {
+    if (!out) return;
+    out->width = 0; out->height = 0;
+    out->samples_per_frame = 1; out->ray_depth = 50; out->max_framebuffer_weight = 1.0f;
+}
+
+void mrt_args_resolve_size(mrt_args* a) {
+    if (!a) return;
+    if (a->width == 0 && a->height == 0) { a->width = MRT_DEFAULT_WIDTH; a->height = MRT_DEFAULT_HEIGHT; }
+    else if (a->width == 0) a->width = a->height;
+    else if (a->height == 0) a->height = a->width;
+}
+
+float mrt_frame_weight(uint32_t frames_done, float max_w) {
+    if (frames_done == 0) return 0.0f;                                 // lib.rs:424
+    const float w = (float)frames_done / (float)(frames_done + 1u);    // lib.rs:304
+    return max_w < w ? max_w : w;                                      // f32::min, lib.rs:301-304
+}
+
+void mrt_pixel_seed(uint64_t seed, uint64_t pixel_index, uint32_t out[4]) {
+    const uint64_t a = splitmix64_at(seed, 2u * pixel_index), b = splitmix64_at(seed, 2u * pixel_index + 1u);
+    out[0] = (uint32_t)a; out[1] = (uint32_t)(a >> 32); out[2] = (uint32_t)b; out[3] = (uint32_t)(b >> 32);
+    if ((out[0] | out[1] | out[2] | out[3]) == 0u) {
+        out[0] = 0x9E3779B9u; out[1] = 0x7F4A7C15u; out[2] = 0xBF58476Du; out[3] = 0x1CE4E5B9u;
+    }
+}
+
+void mrt_frame_shuffle(uint64_t seed, uint32_t frame, uint32_t out[4]) {
+    if (frame == 0) { out[0] = out[1] = out[2] = out[3] = 0; return; }  // lib.rs:422
+    const uint64_t s2 = seed ^ 0xD1B54A32D192ED03ull;
+    const uint64_t a = splitmix64_at(s2, 2ull * frame), b = splitmix64_at(s2, 2ull * frame + 1u);
+    out[0] = (uint32_t)a; out[1] = (uint32_t)(a >> 32); out[2] = (uint32_t)b; out[3] = (uint32_t)(b >> 32);
+}
+
+int mrt_camera_derive(const mrt_camera* cam, mrt_camera_raw* out) {
+    if (!cam || !out) return MRT_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    out->mode = cam->mode;
+    if (cam->mode == 0) return MRT_OK;
+    if (cam->mode != 1) return MRT_ERR_INVALID_ARG;
+    double lf[3], la[3], up[3], w[3], u[3], v[3];
+    for (int i = 0; i < 3; i++) { lf[i] = cam->lookfrom[i]; la[i] = cam->lookat[i]; up[i] = cam->vup[i]; }
+    for (int i = 0; i < 3; i++) w[i] = lf[i] - la[i];
+    const double wl = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    for (int i = 0; i < 3; i++) w[i] /= wl;
+    u[0] = up[1] * w[2] - up[2] * w[1];
+    u[1] = up[2] * w[0] - up[0] * w[2];
+    u[2] = up[0] * w[1] - up[1] * w[0];
+    const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    for (int i = 0; i < 3; i++) u[i] /= ul;
+    v[0] = w[1] * u[2] - w[2] * u[1];
+    v[1] = w[2] * u[0] - w[0] * u[2];
+    v[2] = w[0] * u[1] - w[1] * u[0];
+    const double deg = 3.14159265358979323846 / 180.0;
+    const double focus = cam->focus_dist;
+    const double s = std::tan(0.5 * (double)cam->vfov_deg * deg) * focus;
+    const double r = std::tan(0.5 * (double)cam->defocus_angle_deg * deg) * focus;
+    out->defocus = cam->defocus_angle_deg > 0.0f;
+    for (int i = 0; i < 3; i++) {
+        out->origin[i] = cam->lookfrom[i];
+        out->su[i] = (float)(s * u[i]);
+        out->sv[i] = (float)(s * v[i]);
+        out->fw[i] = (float)(focus * w[i]);
+        out->ru[i] = (float)(r * u[i]);
+        out->rv[i] = (float)(r * v[i]);
+    }
+    for (int i = 0; i < 3; i++)
+        if (!std::isfinite(out->su[i]) || !std::isfinite(out->sv[i]) || !std::isfinite(out->fw[i]) ||
+            !std::isfinite(out->ru[i]) || !std::isfinite(out->rv[i]) || !std::isfinite(out->origin[i]))
+            return MRT_ERR_INVALID_ARG;
+    return MRT_OK;
+}
+
+// lib.rs:722-799
+int mrt_pack_world(const mrt_sphere* sp, size_t n, mrt_world* world,
+                   float* vec4, size_t cap_vec4, size_t* n_vec4,
+                   float* f32, size_t cap_f32, size_t* n_f32,
+                   int32_t* i32, size_t cap_i32, size_t* n_i32) {
+    if ((!sp && n) || !world || !vec4 || !f32 || !i32 || !n_vec4 || !n_f32 || !n_i32) return MRT_ERR_INVALID_ARG;
+    if (n > (size_t)INT32_MAX / 4) return MRT_ERR_INVALID_ARG;
+    size_t nl = 0, nm = 0, nd = 0;
+    for (size_t i = 0; i < n; i++) {
+        switch (sp[i].material_ty) {
+            case MRT_LAMBERTIAN: nl++; break;
+            case MRT_METAL: nm++; break;
+            case MRT_DIELECTRIC: nd++; break;
+            default: return MRT_ERR_BAD_SCENE;
+        }
+    }
+    if (cap_vec4 < n + nl + nm || cap_f32 < n + nm + nd || cap_i32 < 2 * n) return MRT_ERR_TOO_SMALL;
+    std::memset(world, 0, sizeof *world);
+    size_t v = 0, f = 0, k = 0;
+    auto push4 = [&](const float* p) { vec4[4 * v] = p[0]; vec4[4 * v + 1] = p[1]; vec4[4 * v + 2] = p[2]; vec4[4 * v + 3] = 1.0f; v++; };
+    world->spheres.center_base_idx = (int32_t)v;
+    for (size_t i = 0; i < n; i++) push4(sp[i].center);
+    world->spheres.radius_base_idx = (int32_t)f;
+    for (size_t i = 0; i < n; i++) f32[f++] = sp[i].radius;
+    world->spheres.material_ty_base_idx = (int32_t)k;
+    for (size_t i = 0; i < n; i++) i32[k++] = sp[i].material_ty;
+    world->spheres.material_idx_base_idx = (int32_t)k;
+    {
+        int32_t cl = 0, cm = 0, cd = 0;
+        for (size_t i = 0; i < n; i++)
+            i32[k++] = sp[i].material_ty == MRT_LAMBERTIAN ? cl++ : sp[i].material_ty == MRT_METAL ? cm++ : cd++;
+    }
+    world->spheres.length = (int32_t)n;
+    world->lambertians.albedo_base_idx = (int32_t)v;
+    for (size_t i = 0; i < n; i++) if (sp[i].material_ty == MRT_LAMBERTIAN) push4(sp[i].albedo);
+    world->lambertians.length = (int32_t)nl;
+    world->metals.albedo_base_idx = (int32_t)v;
+    for (size_t i = 0; i < n; i++) if (sp[i].material_ty == MRT_METAL) push4(sp[i].albedo);
+    world->metals.fuzz_base_idx = (int32_t)f;
+    for (size_t i = 0; i < n; i++) if (sp[i].material_ty == MRT_METAL) f32[f++] = sp[i].param;
+    world->metals.length = (int32_t)nm;
+    world->dielectrics.ior_base_idx = (int32_t)f;
+    for (size_t i = 0; i < n; i++) if (sp[i].material_ty == MRT_DIELECTRIC) f32[f++] = sp[i].param;
+    world->dielectrics.length = (int32_t)nd;
+    *n_vec4 = v; *n_f32 = f; *n_i32 = k;
+    return MRT_OK;
+}
+
+int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
+    if (!args || !out) return fail(nullptr, MRT_ERR_INVALID_ARG, "mrt_create: null argument");
+    *out = nullptr;
+    mrt_args a = *args;
+    mrt_args_resolve_size(&a);
+    if (a.width > (1u << 20) || a.height > (1u << 20))
+        return fail(nullptr, MRT_ERR_INVALID_ARG, "mrt_create: image %ux%u too large", a.width, a.height);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, MRT_ERR_NO_DEVICE, "mrt_create: no HIP device (this backend has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, MRT_ERR_NO_DEVICE, "mrt_create: device %d out of range (%d present)", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return fail(nullptr, MRT_ERR_NO_DEVICE, "mrt_create: cannot query device %d", device);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MRT_ERR_NO_DEVICE, "mrt_create: device %d is %s; kernels are built for gfx950 only",
+                    device, prop.gcnArchName);
+    mrt_ctx* c = new (std::nothrow) mrt_ctx();
+    if (!c) return fail(nullptr, MRT_ERR_INVALID_ARG, "mrt_create: out of host memory");
+    c->device = device; c->args = a; c->seed = seed;
+    c->camera.mode = 0; c->cam_raw.mode = 0;
+    reset_locals(c);
+    auto bail = [&](int st) { g_err = c->err; mrt_destroy(c); return st; };
+    if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(MRT_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(MRT_ERR_HIP); }
+    c->stream = c->own_stream;
+    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
+    if (hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream) != hipSuccess) { c->err = "counter allocation failed"; return bail(MRT_ERR_HIP); }
+    int st = alloc_frame_buffers(c);
+    if (st != MRT_OK) return bail(st);
+    *out = c;
+    return MRT_OK;
+}
+
+void mrt_destroy(mrt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_frame_buffers(c);
+    free_world(c);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int mrt_set_shard(mrt_ctx* c, uint32_t rank, uint32_t world) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    if (world == 0 || rank >= world) return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_shard: rank %u of %u", rank, world);
+    if (c->frames_done != 0) return fail(c, MRT_ERR_STATE, "mrt_set_shard: frames already rendered; call mrt_reset first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->shard_rank = rank; c->shard_world = world;
+    return alloc_frame_buffers(c);
+}
+
+int mrt_set_stream(mrt_ctx* c, void* s) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return MRT_OK;
+}
+
+int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t n_vec4,
+                      const float* f32, size_t n_f32, const int32_t* i32, size_t n_i32) {
+    if (!c || !w) return MRT_ERR_INVALID_ARG;
+    if ((n_vec4 && !vec4) || (n_f32 && !f32) || (n_i32 && !i32)) return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_world_raw: null array");
+    const int64_t n = w->spheres.length;
+    if (n < 0 || n > (int64_t)mrt::kMaxSpheres) return fail(c, MRT_ERR_BAD_SCENE, "spheres.length %lld out of range [0, %u]", (long long)n, mrt::kMaxSpheres);
+    auto in_range = [](int64_t base, int64_t len, size_t cap) { return base >= 0 && len >= 0 && (uint64_t)(base + len) <= cap; };
+    if (!in_range(w->spheres.center_base_idx, n, n_vec4) || !in_range(w->spheres.radius_base_idx, n, n_f32) ||
+        !in_range(w->spheres.material_ty_base_idx, n, n_i32) || !in_range(w->spheres.material_idx_base_idx, n, n_i32) ||
+        !in_range(w->lambertians.albedo_base_idx, w->lambertians.length, n_vec4) ||
+        !in_range(w->metals.albedo_base_idx, w->metals.length, n_vec4) ||
+        !in_range(w->metals.fuzz_base_idx, w->metals.length, n_f32) ||
+        !in_range(w->dielectrics.ior_base_idx, w->dielectrics.length, n_f32))
+        return fail(c, MRT_ERR_BAD_SCENE, "a World range points outside its data array");
+    // geometry must be finite and moderate so that no discriminant can overflow to inf/NaN
+    const float kLim = 1.0e7f;
+    for (int64_t i = 0; i < n; i++) {
+        const float* ctr = vec4 + 4 * (w->spheres.center_base_idx + i);
+        const float r = f32[w->spheres.radius_base_idx + i];
+        if (!finite_in_range(ctr[0], kLim) || !finite_in_range(ctr[1], kLim) || !finite_in_range(ctr[2], kLim) ||
+            !finite_in_range(r, kLim))
+            return fail(c, MRT_ERR_BAD_SCENE, "sphere %lld: centre/radius not finite or |v| > 1e7", (long long)i);
+        const int32_t ty = i32[w->spheres.material_ty_base_idx + i];
+        const int32_t mi = i32[w->spheres.material_idx_base_idx + i];
+        const int32_t len = ty == MRT_LAMBERTIAN ? w->lambertians.length : ty == MRT_METAL ? w->metals.length
+                          : ty == MRT_DIELECTRIC ? w->dielectrics.length : INT32_MAX;   // unknown ty: absorbs, idx unused
+        if (mi < 0 || (ty >= MRT_LAMBERTIAN && ty <= MRT_DIELECTRIC && mi >= len))
+            return fail(c, MRT_ERR_BAD_SCENE, "sphere %lld: material index %d out of range for type %d", (long long)i, mi, ty);
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_world(c);
+
+    const uint32_t n_padded = (uint32_t)((n + mrt::kChunk - 1) / mrt::kChunk * mrt::kChunk);
+    std::vector<mrt::SphereRec> recs(n_padded ? n_padded : 1);
+    for (uint32_t i = 0; i < n_padded; i++) {
+        if ((int64_t)i < n) {
+            const float* ctr = vec4 + 4 * (w->spheres.center_base_idx + i);
+            const float r = f32[w->spheres.radius_base_idx + i];
+            recs[i] = mrt::SphereRec{ctr[0], ctr[1], ctr[2], -(r * r)};
+        } else {
+            recs[i] = mrt::SphereRec{0.0f, 0.0f, 0.0f, INFINITY};   // discriminant = -inf: never a candidate
+        }
+    }
+    auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+        if (e != hipSuccess || !bytes) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_TRY(c, upload((void**)&c->d_spheres, recs.data(), recs.size() * sizeof(mrt::SphereRec)));
+    HIP_TRY(c, upload((void**)&c->d_vec4, vec4, n_vec4 * 4 * sizeof(float)));
+    HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
+    HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
+    c->world = *w;
+    c->n_spheres = (uint32_t)n;
+    c->n_padded = n_padded;
+    c->have_world = true;
+    return MRT_OK;
+}
+
+int mrt_set_world(mrt_ctx* c, const mrt_sphere* spheres, size_t n) {
+    if (!c || (!spheres && n)) return MRT_ERR_INVALID_ARG;
+    std::vector<float> vec4(8 * n + 4), f32(2 * n + 1);
+    std::vector<int32_t> i32(2 * n + 1);
+    mrt_world w;
+    size_t nv = 0, nf = 0, ni = 0;
+    int st = mrt_pack_world(spheres, n, &w, vec4.data(), 2 * n + 1, &nv, f32.data(), 2 * n + 1, &nf, i32.data(), 2 * n + 1, &ni);
+    if (st != MRT_OK) return fail(c, st, "mrt_set_world: packing failed (%s)", mrt_status_string(st));
+    return mrt_set_world_raw(c, &w, vec4.data(), nv, f32.data(), nf, i32.data(), ni);
+}
+
+int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
+    if (!c || !cam) return MRT_ERR_INVALID_ARG;
+    mrt_camera_raw raw;
+    int st = mrt_camera_derive(cam, &raw);
+    if (st != MRT_OK) return fail(c, st, "mrt_set_camera: degenerate or invalid camera");
+    c->camera = *cam; c->cam_raw = raw;
+    return MRT_OK;
+}
+
+int mrt_shard_info(mrt_ctx* c, uint32_t* rank, uint32_t* world, uint32_t* local_rows, uint32_t* width) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    if (rank) *rank = c->shard_rank;
+    if (world) *world = c->shard_world;
+    if (local_rows) *local_rows = c->local_bands * mrt::kBandRows;
+    if (width) *width = c->args.width;
+    return MRT_OK;
+}
+
+// copy between a full bottom-up image on the host and this shard's packed rows on the device
+static int copy_rows(mrt_ctx* c, void* device_base, void* host_full, size_t texel_bytes, bool to_device) {
+    const uint32_t W = c->args.width, H = c->args.height;
+    const size_t band_bytes = (size_t)mrt::kBandRows * W * texel_bytes;
+    for (uint32_t b = 0; b < c->local_bands; b++) {
+        const uint32_t gb = b * c->shard_world + c->shard_rank;
+        const uint32_t y0 = gb * mrt::kBandRows;
+        if (y0 >= H) break;
+        const uint32_t rows = (H - y0 < mrt::kBandRows) ? H - y0 : mrt::kBandRows;
+        char* dptr = (char*)device_base + b * band_bytes;
+        char* hptr = (char*)host_full + (size_t)y0 * W * texel_bytes;
+        const size_t bytes = (size_t)rows * W * texel_bytes;
+        if (to_device) HIP_TRY(c, hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, c->stream));
+        else HIP_TRY(c, hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MRT_OK;
+}
+
+int mrt_set_seeds(mrt_ctx* c, const uint32_t* seeds, size_t n_u32) {
+    if (!c || !seeds) return MRT_ERR_INVALID_ARG;
+    if (n_u32 != (size_t)c->args.width * c->args.height * 4) return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_seeds: expected W*H*4 u32");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return copy_rows(c, c->d_seeds, const_cast<uint32_t*>(seeds), 16, true);
+}
+
+int mrt_read_seeds(mrt_ctx* c, uint32_t* out, size_t cap) {
+    if (!c || !out) return MRT_ERR_INVALID_ARG;
+    const size_t n = local_texels(c) * 4;
+    if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_read_seeds: need %zu u32", n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_seeds, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MRT_OK;
+}
+
+// State::redraw, lib.rs:241-307 (raytrace pass + swap + weight/shuffle update; the present
+// pass needs a window surface and is out of scope)
+int mrt_redraw(mrt_ctx* c) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    if (!c->have_world) return fail(c, MRT_ERR_NO_SCENE, "mrt_redraw: no scene (call mrt_set_world first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    mrt::KParams p;
+    std::memset(&p, 0, sizeof p);
+    p.locals = c->locals;
+    p.world = c->world;
+    p.cam = c->cam_raw;
+    p.n_spheres = c->n_spheres;
+    p.n_padded = c->n_padded;
+    p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
+    p.spheres = c->d_spheres; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
+    p.seeds = c->d_seeds;
+    p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
+    p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
+    p.counters = c->d_counters;
+    HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    int e = mrt::launch_render(p, c->local_bands, c->stream);
+    if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
+    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->timed = true;
+
+    c->target ^= 1;                                                       // framebuffers.swap(), lib.rs:299
+    if (c->frames_done != UINT32_MAX) c->frames_done++;                   // saturating_add, lib.rs:300
+    c->locals.framebuffer_weight = mrt_frame_weight(c->frames_done, c->args.max_framebuffer_weight);  // :301-304
+    mrt_frame_shuffle(c->seed, c->frames_done, c->locals.rng_shuffle);    // :305 (deterministic stand-in)
+    c->shuffle_overridden = false;
+    return MRT_OK;
+}
+
+int mrt_render(mrt_ctx* c, uint32_t frames) {
+    for (uint32_t i = 0; i < frames; i++) {
+        int st = mrt_redraw(c);
+        if (st != MRT_OK) return st;
+    }
+    return MRT_OK;
+}
+
+int mrt_sync(mrt_ctx* c) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MRT_OK;
+}
+
+int mrt_reset(mrt_ctx* c) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = local_texels(c) * 4 * sizeof(float);
+    HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, bytes, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));
+    const uint32_t spp = c->locals.samples_per_frame;
+    reset_locals(c);
+    c->locals.samples_per_frame = spp;
+    c->target = 0;
+    return MRT_OK;
+}
+
+int mrt_get_locals(mrt_ctx* c, mrt_locals* out) {
+    if (!c || !out) return MRT_ERR_INVALID_ARG;
+    *out = c->locals;
+    return MRT_OK;
+}
+
+int mrt_set_rng_shuffle(mrt_ctx* c, const uint32_t s[4]) {
+    if (!c || !s) return MRT_ERR_INVALID_ARG;
+    std::memcpy(c->locals.rng_shuffle, s, 16);
+    c->shuffle_overridden = true;
+    return MRT_OK;
+}
+
+int mrt_set_samples_per_frame(mrt_ctx* c, uint32_t spp) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    c->locals.samples_per_frame = spp;
+    return MRT_OK;
+}
+
+uint32_t mrt_frames_done(mrt_ctx* c) { return c ? c->frames_done : 0; }
+
+void* mrt_framebuffer_device_ptr(mrt_ctx* c) {
+    if (!c) return nullptr;
+    return c->d_fb[c->target ^ 1];   // after the swap, the last render target is "secondary"
+}
+
+int mrt_read_framebuffer(mrt_ctx* c, float* out, size_t cap) {
+    if (!c || !out) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float* src = c->d_fb[c->target ^ 1];
+    if (c->shard_world == 1) {
+        const size_t n = (size_t)c->args.width * c->args.height * 4;
+        if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_read_framebuffer: need %zu floats", n);
+        return copy_rows(c, src, out, 16, false);
+    }
+    const size_t n = local_texels(c) * 4;
+    if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_read_framebuffer: need %zu floats", n);
+    HIP_TRY(c, hipMemcpyAsync(out, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MRT_OK;
+}
+
+int mrt_read_counters(mrt_ctx* c, mrt_counters* out) {
+    if (!c || !out) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long h[3];
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->samples = h[0]; out->world_hit_calls = h[1]; out->rng_draws = h[2];
+    return MRT_OK;
+}
+
+int mrt_last_kernel_ms(mrt_ctx* c, float* ms) {
+    if (!c || !ms) return MRT_ERR_INVALID_ARG;
+    if (!c->timed) return fail(c, MRT_ERR_STATE, "mrt_last_kernel_ms: nothing rendered yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventSynchronize(c->ev_stop));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return MRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,401 @@
+// HIP kernels for gfx950 (MI355X): the per-pixel render loop of zetanumbers/myraytracer
+// (raytracer/src/shader.wgsl fs_main and everything it calls), rebuilt for CDNA4.
+//
+// Shape of the kernel (see DESIGN.md for the measurements behind each choice):
+//   * one lane = one pixel for the whole frame, as in the fragment shader, so the
+//     reference's one-Xoshiro128+-stream-per-pixel draw order is preserved exactly;
+//   * the sample loop and the bounce loop (shader.wgsl:378, :339) are flattened into ONE
+//     per-lane state machine: every trip of the wave's loop is one `world_hit` for every
+//     live lane, whichever sample / bounce that lane is on, so a lane whose path ended
+//     starts its next sample immediately instead of idling until the wave's longest path
+//     ends;
+//   * `world_hit` (shader.wgsl:314-329) is split into a branch-free discriminant sweep
+//     over all spheres -- sphere records are wave-uniform, so they are fetched by scalar
+//     loads into SGPRs (no LDS, no VGPRs, no per-lane bandwidth) and each test costs 11
+//     fp32 VALU ops + 1 v_alignbit that shifts the sign of the discriminant into a
+//     per-lane 32-sphere bitmask -- and an exact pass over the few spheres whose
+//     discriminant was non-negative, in index order, with the reference's sqrt / divide /
+//     range tests (shader.wgsl:286-296).  Candidate indices wait in an LDS list per lane.
+//   * one coalesced RGBA32F store per pixel per frame; the 8x8 wave tile writes whole
+//     128-byte lines.
+//
+// Arithmetic follows the "MRT-F32" rules: fma only where written, no
+// contraction (-ffp-contract=off), correctly rounded sqrt and divide (hipcc default).
+// The CPU oracle under oracle/ implements the same rules independently; tests require
+// bit-identical framebuffers.
+
+#include <hip/hip_runtime.h>
+#include "mrt_internal.h"
+
+namespace mrt {
+namespace {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+
+// WGSL dot(): x*x first, then fma in y, then fma in z
+__device__ __forceinline__ float dot3(V3 a, V3 b) {
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+}
+// WGSL normalize(e) = e / length(e)
+__device__ __forceinline__ V3 normalize3(V3 v) { return v / __builtin_sqrtf(dot3(v, v)); }
+// WGSL reflect(e1, e2) = e1 - 2*dot(e2, e1)*e2  (shader.wgsl:230)
+__device__ __forceinline__ V3 reflect3(V3 d, V3 n) {
+    float k = 2.0f * dot3(n, d);
+    return v3(d.x - k * n.x, d.y - k * n.y, d.z - k * n.z);
+}
+// WGSL mix(e1, e2, e3) = e1*(1-e3) + e2*e3
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+// ---- Xoshiro128+ (shader.wgsl:36-94) -------------------------------------------------
+struct Rng { uint32_t s0, s1, s2, s3; uint32_t draws; };
+
+__device__ __forceinline__ uint32_t rng_next(Rng& r) {          // shader.wgsl:49-64
+    uint32_t result = r.s0 + r.s3;
+    uint32_t t = r.s1 << 9;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = (r.s3 << 11) | (r.s3 >> 21);                          // rotl_u32(.., 11), :36-38
+    return result;
+}
+__device__ __forceinline__ float rng_f32(Rng& r) {               // shader.wgsl:66-69
+    r.draws++;
+    return (float)rng_next(r) * 0x1p-32f;                        // == f32(i) / 4294967296.0
+}
+__device__ __forceinline__ V3 rng_unit_ball(Rng& r) {            // shader.wgsl:84-90
+    V3 v;
+    do {
+        float x = rng_f32(r); float y = rng_f32(r); float z = rng_f32(r);   // :77-82 order x,y,z
+        v = v3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
+    } while (dot3(v, v) > 1.0f);
+    return v;
+}
+
+// ---- scene access (shader.wgsl:198-201, 218-226, 254-268) ----------------------------
+__device__ __forceinline__ V3 load_vec4_xyz(const float* vec4_data, int32_t idx) {
+    const float4 v = reinterpret_cast<const float4*>(vec4_data)[idx];
+    return v3(v.x, v.y, v.z);
+}
+
+// One exact sphere test for the candidate `idx`: shader.wgsl:274-296 with the hit record
+// deferred (only t and the index are kept; at/normal/material are rebuilt once per bounce
+// from the winning sphere, which gives the same values because they depend only on t).
+__device__ __forceinline__ void exact_test(const SphereRec s, uint32_t idx, V3 o, V3 d, float a,
+                                           float& t_sup, int32_t& best) {
+    V3 oc = v3(o.x - s.cx, o.y - s.cy, o.z - s.cz);
+    float b = dot3(oc, d);
+    float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, s.neg_r2)));
+    float disc = __builtin_fmaf(b, b, -(a * c));
+    if (!(disc < 0.0f)) {                                        // :282
+        float d_sqrt = __builtin_sqrtf(disc);                    // :286
+        const float t_min = 0.001f;                              // :340
+        float t = (-b - d_sqrt) / a;                             // :290
+        if (t < t_min || t_sup <= t) t = (-b + d_sqrt) / a;      // :291-293
+        if (!(t < t_min || t_sup <= t)) {                        // :294-296
+            t_sup = t;                                           // world_hit :322
+            best = (int32_t)idx;
+        }
+    }
+}
+
+// Candidate list: per wave kCandCap entries x 64 lanes of u16, entry-major so that the 64
+// lanes of one push / pop touch 128 consecutive bytes.
+constexpr uint32_t kCandCap = 64;
+constexpr uint32_t kWavesPerBlock = 4;
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256) render_kernel(const KParams P) {
+    __shared__ uint16_t cand_lds[kWavesPerBlock * kCandCap * 64];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint16_t* const cand = cand_lds + wave * (kCandCap * 64u) + lane;   // entry k at cand[k*64]
+
+    const uint32_t W = P.locals.shape[0], H = P.locals.shape[1];
+    const uint32_t px = blockIdx.x * kTileW + wave * 8u + (lane & 7u);
+    const uint32_t lrow = blockIdx.y * kBandRows + (lane >> 3);                       // row in this shard
+    const uint32_t py = (blockIdx.y * P.shard_world + P.shard_rank) * kBandRows + (lane >> 3);  // global row, 0 = bottom
+    const bool valid = (px < W) && (py < H);
+    const size_t texel = (size_t)lrow * W + px;
+
+    const uint32_t spp = P.locals.samples_per_frame;
+    const uint32_t n_padded = P.n_padded;
+    const SphereRec* __restrict__ spheres = P.spheres;
+
+    // fs_main prologue, shader.wgsl:373-377
+    const float pixel_side = 2.0f / (float)H;
+    const float base_x = (((float)px + 0.5f) - 0.5f * (float)W) * pixel_side;
+    const float base_y = (((float)py + 0.5f) - 0.5f * (float)H) * pixel_side;
+
+    Rng rng; rng.draws = 0;
+    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    if (valid) {                                                   // xoshiro128plus_load, :44-47
+        const uint4 s = reinterpret_cast<const uint4*>(P.seeds)[texel];
+        rng.s0 = s.x ^ P.locals.rng_shuffle[0];
+        rng.s1 = s.y ^ P.locals.rng_shuffle[1];
+        rng.s2 = s.z ^ P.locals.rng_shuffle[2];
+        rng.s3 = s.w ^ P.locals.rng_shuffle[3];
+    }
+
+    V3 color = v3(0.0f, 0.0f, 0.0f);
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, -1.0f), att = v3(1.0f, 1.0f, 1.0f);
+    uint32_t depth_left = 0, started = 0, bounces = 0;
+    bool active = valid && spp > 0u;
+    bool need_sample = true;
+
+    while (active) {
+        if (need_sample) {
+            // one trip of the sample loop head, shader.wgsl:378-381
+            float u = rng_f32(rng); float v = rng_f32(rng);            // :71-75, x then y
+            float vx = base_x + u * pixel_side;
+            float vy = base_y + v * pixel_side;
+            if (P.cam.mode == 0) {
+                o = v3(0.0f, 0.0f, 0.0f);                               // ORIGIN, :361
+                d = normalize3(v3(vx, vy, -1.0f));                      // :381
+            } else {
+                // extension: look-at thin-lens camera over the same (vx, vy)
+                V3 p = v3((vx * P.cam.su[0] + vy * P.cam.sv[0]) - P.cam.fw[0],
+                          (vx * P.cam.su[1] + vy * P.cam.sv[1]) - P.cam.fw[1],
+                          (vx * P.cam.su[2] + vy * P.cam.sv[2]) - P.cam.fw[2]);
+                o = v3(P.cam.origin[0], P.cam.origin[1], P.cam.origin[2]);
+                if (P.cam.defocus) {
+                    float lx, ly;
+                    do {                                                // unit disk by rejection
+                        float qx = rng_f32(rng); float qy = rng_f32(rng);
+                        lx = 2.0f * qx - 1.0f; ly = 2.0f * qy - 1.0f;
+                    } while (__builtin_fmaf(ly, ly, lx * lx) > 1.0f);
+                    V3 off = v3(lx * P.cam.ru[0] + ly * P.cam.rv[0],
+                                lx * P.cam.ru[1] + ly * P.cam.rv[1],
+                                lx * P.cam.ru[2] + ly * P.cam.rv[2]);
+                    o = o + off;
+                    d = normalize3(p - off);
+                } else {
+                    d = normalize3(p);
+                }
+            }
+            att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
+            depth_left = P.locals.ray_depth;
+            started++;
+            need_sample = false;
+        }
+
+        bool path_done = false;
+        V3 contrib = v3(0.0f, 0.0f, 0.0f);
+
+        if (depth_left == 0u) {
+            path_done = true;                                           // loop :339 not entered -> :357
+        } else {
+            // ------------------------------------------------ world_hit, shader.wgsl:314-329
+            bounces++;
+            const float a = dot3(d, d);                                 // sphere_hit :277 (same for every sphere)
+            float t_sup = 1.0e4f;                                       // :340
+            int32_t best = -1;
+            // A ray with a non-finite component makes every discriminant NaN, which the
+            // reference treats as "not < 0".  Such lanes take the literal loop below.
+            const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
+                                 __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff());
+            uint32_t cnt = 0;
+            for (uint32_t i = 0; i < n_padded; i += kChunk) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < kChunk; j++) {
+                    const SphereRec s = spheres[i + j];                 // wave-uniform -> s_load
+                    float ocx = o.x - s.cx, ocy = o.y - s.cy, ocz = o.z - s.cz;                         // :274
+                    float b = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));          // :278
+                    float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, s.neg_r2)));  // :279
+                    float disc = __builtin_fmaf(b, b, -(a * c));                                       // :280
+                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(disc), 31);                 // sign(disc) -> bit (31-j)
+                }
+                uint32_t m = weird ? 0u : ~bits;                        // 1 = discriminant >= 0
+                // flush before the list could overflow (never for ordinary scenes)
+                if (cnt + kChunk > kCandCap) {
+                    for (uint32_t k = 0; k < cnt; k++) {
+                        const uint32_t idx = cand[k * 64u];
+                        exact_test(spheres[idx], idx, o, d, a, t_sup, best);
+                    }
+                    cnt = 0;
+                }
+                while (m != 0u) {
+                    const uint32_t j = (uint32_t)__builtin_clz(m);      // lowest sphere index first
+                    m &= ~(0x80000000u >> j);
+                    cand[cnt * 64u] = (uint16_t)(i + j);
+                    cnt++;
+                }
+            }
+            for (uint32_t k = 0; k < cnt; k++) {                        // exact pass, index order
+                const uint32_t idx = cand[k * 64u];
+                exact_test(spheres[idx], idx, o, d, a, t_sup, best);
+            }
+            if (weird) {
+                for (uint32_t idx = 0; idx < P.n_spheres; idx++)
+                    exact_test(spheres[idx], idx, o, d, a, t_sup, best);
+            }
+
+            if (best < 0) {
+                // color_sky, shader.wgsl:331-334, 343-345
+                float t = 0.5f * d.y + 0.5f;
+                contrib = att * v3(mixf(1.0f, 0.5f, t), mixf(1.0f, 0.7f, t), mixf(1.0f, 1.0f, t));
+                path_done = true;
+            } else {
+                // rest of sphere_hit for the winning sphere, shader.wgsl:298-309
+                const V3 center = load_vec4_xyz(P.vec4_data, P.world.spheres.center_base_idx + best);
+                const float radius = P.f32_data[P.world.spheres.radius_base_idx + best];
+                const int32_t m_ty = P.i32_data[P.world.spheres.material_ty_base_idx + best];
+                const int32_t m_idx = P.i32_data[P.world.spheres.material_idx_base_idx + best];
+                const V3 at = o + t_sup * d;                            // ray_normalized_at :103-105
+                V3 normal = (at - center) / radius;
+                const bool front_face = dot3(normal, d) <= 0.0f;
+                if (!front_face) normal = -normal;
+
+                // dyn_material_scatter, shader.wgsl:244-252
+                V3 albedo = v3(1.0f, 1.0f, 1.0f), ndir = d;
+                bool scattered;
+                if (m_ty == MRT_LAMBERTIAN) {                           // :203-216
+                    albedo = load_vec4_xyz(P.vec4_data, P.world.lambertians.albedo_base_idx + m_idx);
+                    ndir = normal + normalize3(rng_unit_ball(rng));     // unit_sphere :92-94
+                    if (dot3(ndir, ndir) == 0.0f) ndir = normal;
+                    scattered = true;
+                } else if (m_ty == MRT_METAL) {                         // :228-242
+                    const V3 refl = reflect3(d, normal);
+                    const float fuzz = P.f32_data[P.world.metals.fuzz_base_idx + m_idx];
+                    const V3 ball = rng_unit_ball(rng);
+                    ndir = v3(refl.x + fuzz * ball.x, refl.y + fuzz * ball.y, refl.z + fuzz * ball.z);
+                    scattered = !(dot3(ndir, normal) <= 0.0f);
+                    albedo = load_vec4_xyz(P.vec4_data, P.world.metals.albedo_base_idx + m_idx);
+                } else if (m_ty == MRT_DIELECTRIC) {                    // extension, DESIGN.md §3
+                    const float ior = P.f32_data[P.world.dielectrics.ior_base_idx + m_idx];
+                    const float ri = front_face ? (1.0f / ior) : ior;
+                    float cos_t = dot3(-d, normal);
+                    cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;
+                    const float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+                    const bool cannot_refract = (ri * sin_t) > 1.0f;
+                    float r0 = (1.0f - ri) / (1.0f + ri);
+                    r0 = r0 * r0;
+                    const float x1 = 1.0f - cos_t;
+                    const float x2 = x1 * x1; const float x4 = x2 * x2; const float x5 = x4 * x1;
+                    const float reflectance = r0 + (1.0f - r0) * x5;
+                    const float u = rng_f32(rng);                       // always exactly one draw
+                    if (cannot_refract || reflectance > u) {
+                        ndir = reflect3(d, normal);
+                    } else {
+                        const V3 perp = v3(ri * (d.x + cos_t * normal.x), ri * (d.y + cos_t * normal.y),
+                                           ri * (d.z + cos_t * normal.z));
+                        const float k = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
+                        ndir = v3(perp.x + k * normal.x, perp.y + k * normal.y, perp.z + k * normal.z);
+                    }
+                    scattered = true;
+                } else {
+                    scattered = false;                                  // :249-251
+                }
+
+                if (!scattered) {
+                    path_done = true;                                   // :349-351 -> vec3(0)
+                } else {
+                    att = att * albedo;                                 // :353
+                    o = at;
+                    d = normalize3(ndir);                               // :354
+                    depth_left--;
+                    if (depth_left == 0u) path_done = true;             // loop ends -> :357 vec3(0)
+                }
+            }
+        }
+
+        if (path_done) {
+            color = color + contrib;                                    // :381
+            if (started < spp) need_sample = true; else active = false;
+        }
+    }
+
+    if (valid) {
+        const float n = (float)spp;
+        color = v3(color.x / n, color.y / n, color.z / n);              // :383
+        const float w = P.locals.framebuffer_weight;
+        const float4 q = reinterpret_cast<const float4*>(P.prev)[texel];   // framebuffer_load :366-369
+        float4 r;
+        r.x = mixf(color.x, q.x, w);                                    // :385
+        r.y = mixf(color.y, q.y, w);
+        r.z = mixf(color.z, q.z, w);
+        r.w = mixf(1.0f, q.w, w);
+        reinterpret_cast<float4*>(P.out)[texel] = r;
+    } else if (px < W) {
+        // padding rows of the last band of a shard: keep them defined
+        reinterpret_cast<float4*>(P.out)[texel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+
+    if (COUNT) {
+        unsigned long long c0 = started, c1 = bounces, c2 = rng.draws;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            c0 += __shfl_xor(c0, off);
+            c1 += __shfl_xor(c1, off);
+            c2 += __shfl_xor(c2, off);
+        }
+        if (lane == 0 && P.counters) {
+            atomicAdd(P.counters + 0, c0);
+            atomicAdd(P.counters + 1, c1);
+            atomicAdd(P.counters + 2, c2);
+        }
+    }
+}
+
+// Seed texture (Subject::new, lib.rs:389-415) generated on the device: SplitMix64 used as a
+// counter-based generator keyed by the GLOBAL pixel index, two outputs per pixel.
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1u) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64_t seed, uint32_t W, uint32_t H,
+                                                         uint32_t shard_rank, uint32_t shard_world,
+                                                         uint32_t local_rows) {
+    const uint32_t px = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lrow = blockIdx.y;
+    if (px >= W || lrow >= local_rows) return;
+    const uint32_t py = ((lrow / kBandRows) * shard_world + shard_rank) * kBandRows + (lrow % kBandRows);
+    uint4 s = make_uint4(0, 0, 0, 0);
+    if (py < H) {
+        const uint64_t p = (uint64_t)py * W + px;
+        const uint64_t a = splitmix64_at(seed, 2u * p), b = splitmix64_at(seed, 2u * p + 1u);
+        s = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+        if ((s.x | s.y | s.z | s.w) == 0u)                             // lib.rs:393 filter
+            s = make_uint4(0x9E3779B9u, 0x7F4A7C15u, 0xBF58476Du, 0x1CE4E5B9u);
+    }
+    reinterpret_cast<uint4*>(seeds)[(size_t)lrow * W + px] = s;
+}
+
+}  // namespace
+
+int launch_render(const KParams& p, uint32_t local_bands, void* stream) {
+    const uint32_t W = p.locals.shape[0];
+    if (W == 0 || local_bands == 0) return 0;
+    dim3 grid((W + kTileW - 1) / kTileW, local_bands), block(256);
+    if (p.counters)
+        hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+int launch_fill_seeds(uint32_t* seeds, uint64_t seed, uint32_t width, uint32_t height,
+                      uint32_t shard_rank, uint32_t shard_world, uint32_t local_bands, void* stream) {
+    if (width == 0 || local_bands == 0) return 0;
+    const uint32_t local_rows = local_bands * kBandRows;
+    dim3 grid((width + 255) / 256, local_rows), block(256);
+    hipLaunchKernelGGL(fill_seeds_kernel, grid, block, 0, (hipStream_t)stream, seeds, seed, width, height,
+                       shard_rank, shard_world, local_rows);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mrt

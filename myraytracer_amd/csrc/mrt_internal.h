@@ -1,0 +1,44 @@
+// Internal types shared by the HIP kernels (kernels.hip) and the host side of the C ABI
+// (api.cpp).  Not installed; the public contract is include/myraytracer_amd.h.
+#pragma once
+#include <stdint.h>
+#include "../../include/myraytracer_amd.h"
+
+namespace mrt {
+
+constexpr uint32_t kBandRows = 8;        // shard granule: 8 image rows (one row of 8x8 wave tiles)
+constexpr uint32_t kTileW = 32;          // a 256-thread workgroup covers 32x8 pixels = 4 wave tiles
+constexpr uint32_t kChunk = 32;          // spheres per unrolled chunk of the discriminant loop
+constexpr uint32_t kMaxSpheres = 65535;  // candidate indices are stored as u16 in LDS
+
+// (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
+// the host from the reference's SoA arrays (centres: vec4_f32_data, radii: f32_data;
+// lib.rs:722-799) and padded to a multiple of kChunk with never-hit entries (w = +inf).
+struct alignas(16) SphereRec { float cx, cy, cz, neg_r2; };
+
+// Everything one raytrace pass needs, passed by value as kernel arguments (-> SGPRs).
+// Mirrors the three bind groups of State::redraw (lib.rs:262-265): Locals + seeds,
+// World + data arrays, previous framebuffer.
+struct KParams {
+    mrt_locals locals;          // shader.wgsl:8-17
+    mrt_world world;            // shader.wgsl:178-182 (+ dielectric range)
+    mrt_camera_raw cam;
+    uint32_t n_spheres;         // world.spheres.length
+    uint32_t n_padded;          // multiple of kChunk
+    uint32_t shard_rank, shard_world;
+    const SphereRec* spheres;   // n_padded records
+    const float* vec4_data;     // r_vec4_f32_data (shader.wgsl:189-190), 4 floats per texel
+    const float* f32_data;      // r_f32_data
+    const int32_t* i32_data;    // r_i32_data
+    const uint32_t* seeds;      // r_rands: local_rows x W x [u32;4]
+    const float* prev;          // r_framebuffer: local_rows x W x rgba
+    float* out;                 // render target
+    unsigned long long* counters;  // 3 x u64 (mrt_counters) or null
+};
+
+// host-callable launchers (kernels.hip)
+int launch_render(const KParams& p, uint32_t local_bands, void* stream);
+int launch_fill_seeds(uint32_t* seeds, uint64_t seed, uint32_t width, uint32_t height,
+                      uint32_t shard_rank, uint32_t shard_world, uint32_t local_bands, void* stream);
+
+}  // namespace mrt

@@ -1,0 +1,84 @@
+// Headless counterpart of native-runner/src/main.rs: the same five flags
+// (main.rs:20-31: --width --height --samples-per-frame --ray-depth --max-framebuffer-weight)
+// driving the MI355X backend through the C ABI, plus what a windowless run needs
+// (--frames, --seed, --scene, --out, --device).  The reference renders forever into a
+// window (lib.rs:187-192); this renders --frames frames and writes the image.
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/myraytracer_amd.h"
+
+static void usage() {
+    std::fprintf(stderr,
+        "usage: native_runner [--width N] [--height N] [--samples-per-frame N] [--ray-depth N]\n"
+        "                     [--max-framebuffer-weight F] [--frames N] [--seed N]\n"
+        "                     [--scene default|cover|cover-glass|stress] [--out FILE.pfm|FILE.ppm] [--device N]\n");
+}
+
+int main(int argc, char** argv) {
+    mrt_args args;
+    mrt_args_default(&args);
+    uint32_t frames = 1; uint64_t seed = 1; int device = 0;
+    std::string scene = "default", out;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i], v;
+        size_t eq = a.find('=');
+        if (eq != std::string::npos) { v = a.substr(eq + 1); a = a.substr(0, eq); }
+        else if (a == "--help" || a == "-h") { usage(); return 0; }
+        else if (i + 1 < argc) v = argv[++i];
+        else { usage(); return 2; }
+        if (a == "--width") args.width = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+        else if (a == "--height") args.height = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+        else if (a == "--samples-per-frame") args.samples_per_frame = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+        else if (a == "--ray-depth") args.ray_depth = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+        else if (a == "--max-framebuffer-weight") args.max_framebuffer_weight = std::strtof(v.c_str(), nullptr);
+        else if (a == "--frames") frames = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+        else if (a == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10);
+        else if (a == "--scene") scene = v;
+        else if (a == "--out") out = v;
+        else if (a == "--device") device = std::atoi(v.c_str());
+        else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return 2; }
+    }
+    mrt_args_resolve_size(&args);
+
+    std::vector<mrt_sphere> spheres(70000);
+    mrt_camera cam; std::memset(&cam, 0, sizeof cam);
+    int n;
+    if (scene == "default") n = mrt_scene_default(spheres.data(), spheres.size());
+    else if (scene == "cover") n = mrt_scene_cover(1, 0, spheres.data(), spheres.size(), &cam);
+    else if (scene == "cover-glass") n = mrt_scene_cover(1, 1, spheres.data(), spheres.size(), &cam);
+    else if (scene == "stress") n = mrt_scene_stress(1, 100, spheres.data(), spheres.size(), &cam);
+    else { std::fprintf(stderr, "unknown scene %s\n", scene.c_str()); return 2; }
+    if (n < 0) { std::fprintf(stderr, "scene generation failed\n"); return 1; }
+
+    mrt_ctx* ctx = nullptr;
+    int st = mrt_create(&args, seed, device, &ctx);
+    if (st != MRT_OK) { std::fprintf(stderr, "mrt_create: %s (%s)\n", mrt_status_string(st), mrt_last_error(nullptr)); return 1; }
+#define TRY(call) do { int s_ = (call); if (s_ != MRT_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, mrt_status_string(s_), mrt_last_error(ctx)); mrt_destroy(ctx); return 1; } } while (0)
+    TRY(mrt_set_world(ctx, spheres.data(), (size_t)n));
+    TRY(mrt_set_camera(ctx, &cam));
+    TRY(mrt_sync(ctx));
+    auto t0 = std::chrono::steady_clock::now();
+    TRY(mrt_render(ctx, frames));
+    TRY(mrt_sync(ctx));
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double samples = (double)args.width * args.height * args.samples_per_frame * frames;
+    std::printf("%ux%u, %u spp x %u frames, depth %u, %d spheres: %.3f s, %.1f Msamples/s\n", args.width, args.height,
+                args.samples_per_frame, frames, args.ray_depth, n, sec, samples / sec * 1e-6);
+    if (!out.empty()) {
+        std::vector<float> fb((size_t)args.width * args.height * 4);
+        TRY(mrt_read_framebuffer(ctx, fb.data(), fb.size()));
+        const bool ppm = out.size() > 4 && out.substr(out.size() - 4) == ".ppm";
+        int s2 = ppm ? mrt_write_ppm(out.c_str(), fb.data(), args.width, args.height)
+                     : mrt_write_pfm(out.c_str(), fb.data(), args.width, args.height);
+        if (s2 != MRT_OK) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); mrt_destroy(ctx); return 1; }
+        std::printf("wrote %s\n", out.c_str());
+    }
+    mrt_destroy(ctx);
+    return 0;
+}

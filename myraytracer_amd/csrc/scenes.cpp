@@ -1,0 +1,120 @@
+// Scene builders (host only).  mrt_scene_default is the reference's hard-coded scene
+// (raytracer/src/lib.rs:687-720); the other two are the synthetic inputs SURVEY.md §8(d)
+// prescribes for configs C2-C5 and have no reference counterpart.  They produce the
+// api::World-style AoS (lib.rs:611-639) that mrt_set_world packs.
+
+#include <cmath>
+#include <cstring>
+
+#include "mrt_internal.h"
+
+namespace {
+
+// scene-generation RNG: sequential SplitMix64, 24-bit floats in [0,1)
+struct SceneRng {
+    uint64_t s;
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    float unit() { return (float)(next() >> 40) * 0x1p-24f; }
+    float range(float lo, float hi) { return lo + (hi - lo) * unit(); }
+};
+
+mrt_sphere make(float x, float y, float z, float r, int32_t ty, float ar, float ag, float ab, float param) {
+    mrt_sphere s;
+    s.center[0] = x; s.center[1] = y; s.center[2] = z; s.radius = r; s.material_ty = ty;
+    s.albedo[0] = ar; s.albedo[1] = ag; s.albedo[2] = ab; s.param = param;
+    return s;
+}
+
+struct Sink {
+    mrt_sphere* out; size_t cap; size_t n = 0;
+    void push(const mrt_sphere& s) { if (out && n < cap) out[n] = s; n++; }
+};
+
+void lookat(mrt_camera* c, float fx, float fy, float fz, float ax, float ay, float az, float vfov, float defocus, float focus) {
+    if (!c) return;
+    std::memset(c, 0, sizeof *c);
+    c->mode = 1;
+    c->lookfrom[0] = fx; c->lookfrom[1] = fy; c->lookfrom[2] = fz;
+    c->lookat[0] = ax; c->lookat[1] = ay; c->lookat[2] = az;
+    c->vup[0] = 0.0f; c->vup[1] = 1.0f; c->vup[2] = 0.0f;
+    c->vfov_deg = vfov; c->defocus_angle_deg = defocus; c->focus_dist = focus;
+}
+
+}  // namespace
+
+extern "C" {
+
+// lib.rs:687-720
+int mrt_scene_default(mrt_sphere* out, size_t cap) {
+    Sink k{out, cap};
+    k.push(make(0.0f, -100.5f, -1.0f, 100.0f, MRT_LAMBERTIAN, 0.8f, 0.8f, 0.0f, 0.0f));
+    k.push(make(0.0f, 0.0f, -1.0f, 0.5f, MRT_LAMBERTIAN, 0.7f, 0.3f, 0.3f, 0.0f));
+    k.push(make(-1.0f, 0.0f, -1.0f, 0.5f, MRT_METAL, 0.8f, 0.8f, 0.8f, 0.3f));
+    k.push(make(1.0f, 0.0f, -1.0f, 0.5f, MRT_METAL, 0.8f, 0.6f, 0.2f, 1.0f));
+    return (int)k.n;
+}
+
+// "Ray Tracing in One Weekend" cover scene in the reference's conventions.
+int mrt_scene_cover(uint64_t scene_seed, int dielectric, mrt_sphere* out, size_t cap, mrt_camera* cam_out) {
+    Sink k{out, cap};
+    SceneRng rng{scene_seed};
+    k.push(make(0.0f, -1000.0f, 0.0f, 1000.0f, MRT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 0.0f));
+    for (int a = -11; a < 11; a++) {
+        for (int b = -11; b < 11; b++) {
+            const float choose = rng.unit();
+            const float cx = (float)a + 0.9f * rng.unit();
+            const float cz = (float)b + 0.9f * rng.unit();
+            const float dx = cx - 4.0f, dz = cz;
+            if (std::sqrt(dx * dx + dz * dz) <= 0.9f) continue;
+            if (choose < 0.8f) {
+                const float r0 = rng.unit() * rng.unit(), g0 = rng.unit() * rng.unit(), b0 = rng.unit() * rng.unit();
+                k.push(make(cx, 0.2f, cz, 0.2f, MRT_LAMBERTIAN, r0, g0, b0, 0.0f));
+            } else if (choose < 0.95f) {
+                const float r0 = rng.range(0.5f, 1.0f), g0 = rng.range(0.5f, 1.0f), b0 = rng.range(0.5f, 1.0f);
+                const float fuzz = rng.range(0.0f, 0.5f);
+                k.push(make(cx, 0.2f, cz, 0.2f, MRT_METAL, r0, g0, b0, fuzz));
+            } else if (dielectric) {
+                k.push(make(cx, 0.2f, cz, 0.2f, MRT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 1.5f));
+            } else {
+                k.push(make(cx, 0.2f, cz, 0.2f, MRT_METAL, 0.9f, 0.9f, 0.9f, 0.0f));
+            }
+        }
+    }
+    if (dielectric) k.push(make(0.0f, 1.0f, 0.0f, 1.0f, MRT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 1.5f));
+    else k.push(make(0.0f, 1.0f, 0.0f, 1.0f, MRT_METAL, 0.9f, 0.9f, 0.9f, 0.0f));
+    k.push(make(-4.0f, 1.0f, 0.0f, 1.0f, MRT_LAMBERTIAN, 0.4f, 0.2f, 0.1f, 0.0f));
+    k.push(make(4.0f, 1.0f, 0.0f, 1.0f, MRT_METAL, 0.7f, 0.6f, 0.5f, 0.0f));
+    lookat(cam_out, 13.0f, 2.0f, 3.0f, 0.0f, 0.0f, 0.0f, 20.0f, dielectric ? 0.6f : 0.0f, 10.0f);
+    return (int)k.n;
+}
+
+// Stress scene: ground + n_side^2 small spheres on a jittered unit grid, 80/15/5 % L/M/D.
+int mrt_scene_stress(uint64_t scene_seed, uint32_t n_side, mrt_sphere* out, size_t cap, mrt_camera* cam_out) {
+    if (n_side == 0 || n_side > 250) return -MRT_ERR_INVALID_ARG;
+    Sink k{out, cap};
+    SceneRng rng{scene_seed};
+    k.push(make(0.0f, -1000.0f, 0.0f, 1000.0f, MRT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 0.0f));
+    const float half = 0.5f * (float)n_side;
+    for (uint32_t a = 0; a < n_side; a++) {
+        for (uint32_t b = 0; b < n_side; b++) {
+            const float r = rng.range(0.1f, 0.2f);
+            const float cx = (float)a - half + 0.6f * rng.unit();
+            const float cz = (float)b - half + 0.6f * rng.unit();
+            const float choose = rng.unit();
+            const float r0 = rng.unit(), g0 = rng.unit(), b0 = rng.unit(), p0 = rng.unit();
+            if (choose < 0.8f) k.push(make(cx, r, cz, r, MRT_LAMBERTIAN, r0 * r0, g0 * g0, b0 * b0, 0.0f));
+            else if (choose < 0.95f) k.push(make(cx, r, cz, r, MRT_METAL, 0.5f + 0.5f * r0, 0.5f + 0.5f * g0, 0.5f + 0.5f * b0, 0.5f * p0));
+            else k.push(make(cx, r, cz, r, MRT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 1.5f));
+        }
+    }
+    const float s = (float)n_side;
+    lookat(cam_out, 0.0f, 0.4f * s, 0.9f * s, 0.0f, 0.0f, 0.0f, 40.0f, 0.0f, 10.0f);
+    return (int)k.n;
+}
+
+}  // extern "C"
