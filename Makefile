@@ -30,3 +30,8 @@ clean:
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean
+
+# diagnostic build with s_memtime phase stamps (scripts/phase_profile.py); not the product
+stamps: $(SRCS) $(HDRS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $(LIBDIR)/libmyraytracer_amd_stamps.so $(SRCS)

@@ -117,6 +117,8 @@ typedef struct {
     uint64_t samples;              /* camera rays started */
     uint64_t world_hit_calls;      /* = bounces; sphere tests = world_hit_calls * spheres.length */
     uint64_t rng_draws;            /* xoshiro128+ outputs consumed */
+    uint64_t lane_slots;           /* 64 x trips of each wave's bounce loop: world_hit_calls / lane_slots
+                                      = SIMD lane utilisation of the kernel (diagnostic, not in the oracle) */
 } mrt_counters;
 
 typedef struct mrt_ctx mrt_ctx;
@@ -204,9 +206,14 @@ void* mrt_framebuffer_device_ptr(mrt_ctx* ctx);
  * world  > 1: this shard's packed rows, local_rows*width*4 floats. */
 int mrt_read_framebuffer(mrt_ctx* ctx, float* rgba_out, size_t cap_floats);
 int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since create/reset */
+/* Diagnostic: the 16 raw u64 counter slots (0..3 = mrt_counters; 4.. are phase cycle sums
+ * written only by the -DMRT_STAMPS profiling build). */
+int mrt_debug_read_counters(mrt_ctx* ctx, uint64_t out[16]);
 /* Elapsed GPU time (ms) of the most recent redraw's render kernel, from HIP events on
  * the launch stream.  Synchronises on the stop event. */
 int mrt_last_kernel_ms(mrt_ctx* ctx, float* ms);
+/* The same for the n <= min(cap, 64) most recent redraws, oldest first. */
+int mrt_kernel_ms_history(mrt_ctx* ctx, float* ms, size_t cap, size_t* n_out);
 
 const char* mrt_last_error(mrt_ctx* ctx);       /* never NULL; ctx may be NULL */
 const char* mrt_status_string(int status);

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmyraytracer_amd.so")
+LIB_PATH = os.environ.get("MRT_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libmyraytracer_amd.so")
 
 # every symbol include/myraytracer_amd.h declares (tests/test_abi.py checks this list
 # against the header and against the loaded library)
@@ -19,6 +19,7 @@ EXPORTS = [
     "mrt_reset", "mrt_get_locals", "mrt_set_rng_shuffle", "mrt_set_samples_per_frame",
     "mrt_frames_done", "mrt_frame_weight", "mrt_frame_shuffle", "mrt_pixel_seed", "mrt_shard_info",
     "mrt_framebuffer_device_ptr", "mrt_read_framebuffer", "mrt_read_counters", "mrt_last_kernel_ms",
+    "mrt_kernel_ms_history", "mrt_debug_read_counters",
     "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_scene_default", "mrt_scene_cover",
     "mrt_scene_stress", "mrt_write_pfm", "mrt_write_ppm",
 ]
@@ -75,7 +76,8 @@ class MrtCameraRaw(C.Structure):
 
 
 class MrtCounters(C.Structure):
-    _fields_ = [("samples", C.c_uint64), ("world_hit_calls", C.c_uint64), ("rng_draws", C.c_uint64)]
+    _fields_ = [("samples", C.c_uint64), ("world_hit_calls", C.c_uint64), ("rng_draws", C.c_uint64),
+                ("lane_slots", C.c_uint64)]
 
 
 _lib = None
@@ -124,6 +126,8 @@ def load():
         "mrt_read_framebuffer": (i32, [vp, vp, sz]),
         "mrt_read_counters": (i32, [vp, P(MrtCounters)]),
         "mrt_last_kernel_ms": (i32, [vp, P(f32)]),
+        "mrt_kernel_ms_history": (i32, [vp, P(f32), sz, P(sz)]),
+        "mrt_debug_read_counters": (i32, [vp, P(u64)]),
         "mrt_last_error": (C.c_char_p, [vp]),
         "mrt_status_string": (C.c_char_p, [i32]),
         "mrt_abi_version": (i32, []),

@@ -312,7 +312,15 @@ class State:
     def read_counters(self) -> dict:
         c = MrtCounters()
         self._check(self._L.mrt_read_counters(self._ctx, C.byref(c)), "mrt_read_counters")
-        return {"samples": int(c.samples), "world_hit_calls": int(c.world_hit_calls), "rng_draws": int(c.rng_draws)}
+        return {"samples": int(c.samples), "world_hit_calls": int(c.world_hit_calls), "rng_draws": int(c.rng_draws),
+                "lane_slots": int(c.lane_slots)}
+
+    def kernel_ms_history(self, n: int = 64) -> list:
+        """GPU time (ms, HIP events on the launch stream) of the render kernel of the last <= n redraws."""
+        buf = (C.c_float * n)()
+        got = C.c_size_t()
+        self._check(self._L.mrt_kernel_ms_history(self._ctx, buf, n, C.byref(got)), "mrt_kernel_ms_history")
+        return [float(buf[i]) for i in range(got.value)]
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

@@ -56,8 +56,10 @@ struct mrt_ctx {
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timed = false;
+    // ring of HIP event pairs around the render kernel of the most recent redraws
+    static constexpr uint32_t kEventRing = 64;
+    hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
+    uint64_t timed_frames = 0;             // redraws recorded so far
 
     std::string err;
 };
@@ -313,9 +315,10 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(MRT_ERR_HIP); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(MRT_ERR_HIP); }
     c->stream = c->own_stream;
-    if (hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
-    if (hipMalloc(&c->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream) != hipSuccess) { c->err = "counter allocation failed"; return bail(MRT_ERR_HIP); }
+    for (uint32_t i = 0; i < mrt_ctx::kEventRing; i++)
+        if (hipEventCreate(&c->ev_start[i]) != hipSuccess || hipEventCreate(&c->ev_stop[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
+    if (hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) { c->err = "counter allocation failed"; return bail(MRT_ERR_HIP); }
     int st = alloc_frame_buffers(c);
     if (st != MRT_OK) return bail(st);
     *out = c;
@@ -329,8 +332,10 @@ void mrt_destroy(mrt_ctx* c) {
     free_frame_buffers(c);
     free_world(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (uint32_t i = 0; i < mrt_ctx::kEventRing; i++) {
+        if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
+        if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -497,11 +502,12 @@ int mrt_redraw(mrt_ctx* c) {
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
     p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
     p.counters = c->d_counters;
-    HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    const uint32_t slot = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
+    HIP_TRY(c, hipEventRecord(c->ev_start[slot], c->stream));
     int e = mrt::launch_render(p, c->local_bands, c->stream);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
-    HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
-    c->timed = true;
+    HIP_TRY(c, hipEventRecord(c->ev_stop[slot], c->stream));
+    c->timed_frames++;
 
     c->target ^= 1;                                                       // framebuffers.swap(), lib.rs:299
     if (c->frames_done != UINT32_MAX) c->frames_done++;                   // saturating_add, lib.rs:300
@@ -532,7 +538,7 @@ int mrt_reset(mrt_ctx* c) {
     const size_t bytes = local_texels(c) * 4 * sizeof(float);
     HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, bytes, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     const uint32_t spp = c->locals.samples_per_frame;
     reset_locals(c);
     c->locals.samples_per_frame = spp;
@@ -585,20 +591,41 @@ int mrt_read_framebuffer(mrt_ctx* c, float* out, size_t cap) {
 int mrt_read_counters(mrt_ctx* c, mrt_counters* out) {
     if (!c || !out) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    unsigned long long h[3];
+    unsigned long long h[4];
     HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    out->samples = h[0]; out->world_hit_calls = h[1]; out->rng_draws = h[2];
+    out->samples = h[0]; out->world_hit_calls = h[1]; out->rng_draws = h[2]; out->lane_slots = h[3];
+    return MRT_OK;
+}
+
+// diagnostic: all 16 raw counter slots (slots 4.. are only written by -DMRT_STAMPS builds)
+int mrt_debug_read_counters(mrt_ctx* c, uint64_t out[16]) {
+    if (!c || !out) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MRT_OK;
+}
+
+int mrt_kernel_ms_history(mrt_ctx* c, float* ms, size_t cap, size_t* n_out) {
+    if (!c || !ms || !n_out) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = c->timed_frames < mrt_ctx::kEventRing ? (size_t)c->timed_frames : mrt_ctx::kEventRing;
+    if (n > cap) n = cap;
+    for (size_t i = 0; i < n; i++) {          // ms[0] = oldest of the n most recent redraws
+        const uint32_t slot = (uint32_t)((c->timed_frames - n + i) % mrt_ctx::kEventRing);
+        HIP_TRY(c, hipEventSynchronize(c->ev_stop[slot]));
+        HIP_TRY(c, hipEventElapsedTime(&ms[i], c->ev_start[slot], c->ev_stop[slot]));
+    }
+    *n_out = n;
     return MRT_OK;
 }
 
 int mrt_last_kernel_ms(mrt_ctx* c, float* ms) {
     if (!c || !ms) return MRT_ERR_INVALID_ARG;
-    if (!c->timed) return fail(c, MRT_ERR_STATE, "mrt_last_kernel_ms: nothing rendered yet");
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipEventSynchronize(c->ev_stop));
-    HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
-    return MRT_OK;
+    if (!c->timed_frames) return fail(c, MRT_ERR_STATE, "mrt_last_kernel_ms: nothing rendered yet");
+    size_t n = 0;
+    return mrt_kernel_ms_history(c, ms, 1, &n);
 }
 
 }  // extern "C"

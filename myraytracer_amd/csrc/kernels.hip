@@ -108,8 +108,67 @@ __device__ __forceinline__ void exact_test(const SphereRec s, uint32_t idx, V3 o
     }
 }
 
+// ---- the discriminant sweep over wave-uniform sphere records --------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// four SphereRec = 16 dwords = one s_load_dwordx16 from the constant address space
+typedef const f32x16 __attribute__((address_space(4)))* SphQuadPtr;
+struct Sph8 { f32x16 lo, hi; };
+
+// Scalar loads are issued and waited for by hand (inline asm): hipcc schedules every
+// s_load of an unrolled body first and then spills the SGPRs, and its waitcnt pass can only
+// emit lgkmcnt(0) -- scalar loads return out of order -- which would also wait for a
+// prefetch.  An asm load is invisible to that pass, so each group is tied to its own wait:
+// smem_wait() "redefines" the group, and every use of the group therefore follows the wait.
+__device__ __forceinline__ void smem_load8(Sph8& g, SphQuadPtr quads, uint32_t first_sphere) {
+    const SphQuadPtr p = quads + first_sphere / 4u;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40"
+                 : "=&s"(g.lo), "=&s"(g.hi) : "s"(p));
+}
+// One statement = "group `cur` has landed; start fetching group `nxt`".  `bits` (produced by
+// the previous group's tests) rides along so that those tests are scheduled BEFORE this
+// point and the tests of `cur` after it, i.e. while the loads of `nxt` are in flight.
+__device__ __forceinline__ void smem_wait_then_load8(Sph8& cur, Sph8& nxt, SphQuadPtr quads, uint32_t first_sphere,
+                                                     uint32_t& bits) {
+    const SphQuadPtr p = quads + first_sphere / 4u;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %2, %5, 0x0\n\ts_load_dwordx16 %3, %5, 0x40"
+                 : "+s"(cur.lo), "+s"(cur.hi), "=&s"(nxt.lo), "=&s"(nxt.hi), "+v"(bits) : "s"(p));
+}
+// sphere_hit up to the discriminant, shader.wgsl:274-282; sign(disc) is shifted into `bits`
+__device__ __forceinline__ void test1(float cx, float cy, float cz, float neg_r2, V3 o, V3 d, float a, uint32_t& bits) {
+    const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;                                             // :274
+    const float b = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));                          // :278
+    const float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, neg_r2)));  // :279
+    const float disc = __builtin_fmaf(b, b, -(a * c));                                                      // :280
+    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(disc), 31);    // oldest sphere ends in the top bit
+}
+__device__ __forceinline__ void test4(const f32x16 q, V3 o, V3 d, float a, uint32_t& bits) {
+    test1(q[0], q[1], q[2], q[3], o, d, a, bits);
+    test1(q[4], q[5], q[6], q[7], o, d, a, bits);
+    test1(q[8], q[9], q[10], q[11], o, d, a, bits);
+    test1(q[12], q[13], q[14], q[15], o, d, a, bits);
+}
+__device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 d, float a, uint32_t& bits) {
+    test4(g.lo, o, d, a, bits);
+    test4(g.hi, o, d, a, bits);
+}
+
 // Candidate list: per wave kCandCap entries x 64 lanes of u16, entry-major so that the 64
 // lanes of one push / pop touch 128 consecutive bytes.
+// Diagnostic build only (-DMRT_STAMPS, scripts/phase_profile.sh): s_memtime shares of the
+// phases of the bounce loop, summed per wave into counters[4..].  Never in the product .so.
+#ifdef MRT_STAMPS
+#define MRT_STAMP(k)                                                        \
+    do {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();                 \
+        phase_[k] += now_ - last_;                                          \
+        last_ = now_;                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+#else
+#define MRT_STAMP(k) do { } while (0)
+#endif
+
 constexpr uint32_t kCandCap = 64;
 constexpr uint32_t kWavesPerBlock = 4;
 
@@ -131,6 +190,7 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
     const uint32_t spp = P.locals.samples_per_frame;
     const uint32_t n_padded = P.n_padded;
     const SphereRec* __restrict__ spheres = P.spheres;
+    const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.spheres;
 
     // fs_main prologue, shader.wgsl:373-377
     const float pixel_side = 2.0f / (float)H;
@@ -149,11 +209,18 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
 
     V3 color = v3(0.0f, 0.0f, 0.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, -1.0f), att = v3(1.0f, 1.0f, 1.0f);
-    uint32_t depth_left = 0, started = 0, bounces = 0;
+    uint32_t depth_left = 0, started = 0, bounces = 0, trips = 0;
     bool active = valid && spp > 0u;
     bool need_sample = true;
 
+#ifdef MRT_STAMPS
+    uint64_t phase_[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t last_ = __builtin_amdgcn_s_memtime();
+#endif
+
     while (active) {
+        trips++;
+        MRT_STAMP(5);
         if (need_sample) {
             // one trip of the sample loop head, shader.wgsl:378-381
             float u = rng_f32(rng); float v = rng_f32(rng);            // :71-75, x then y
@@ -188,6 +255,7 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
             started++;
             need_sample = false;
         }
+        MRT_STAMP(0);
 
         bool path_done = false;
         V3 contrib = v3(0.0f, 0.0f, 0.0f);
@@ -205,17 +273,20 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
             const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
                                  __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff());
             uint32_t cnt = 0;
+            // Discriminant sweep.  Sphere records are wave-uniform: they are fetched with scalar
+            // loads, 8 records (two s_load_dwordx16 = 32 SGPRs) per group, double-buffered:
+            // wait for group g, issue the loads of group g+1, then run the 8 x 12 VALU ops of
+            // group g while they fly.
+            Sph8 ga, gb;
+            smem_load8(ga, sph_quads, 0u);
             for (uint32_t i = 0; i < n_padded; i += kChunk) {
                 uint32_t bits = 0;
-#pragma unroll
-                for (uint32_t j = 0; j < kChunk; j++) {
-                    const SphereRec s = spheres[i + j];                 // wave-uniform -> s_load
-                    float ocx = o.x - s.cx, ocy = o.y - s.cy, ocz = o.z - s.cz;                         // :274
-                    float b = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));          // :278
-                    float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, s.neg_r2)));  // :279
-                    float disc = __builtin_fmaf(b, b, -(a * c));                                       // :280
-                    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(disc), 31);                 // sign(disc) -> bit (31-j)
-                }
+                smem_wait_then_load8(ga, gb, sph_quads, i + 8u, bits);  test8(ga, o, d, a, bits);
+                smem_wait_then_load8(gb, ga, sph_quads, i + 16u, bits); test8(gb, o, d, a, bits);
+                smem_wait_then_load8(ga, gb, sph_quads, i + 24u, bits); test8(ga, o, d, a, bits);
+                const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
+                smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);     test8(gb, o, d, a, bits);
+                MRT_STAMP(1);
                 uint32_t m = weird ? 0u : ~bits;                        // 1 = discriminant >= 0
                 // flush before the list could overflow (never for ordinary scenes)
                 if (cnt + kChunk > kCandCap) {
@@ -231,7 +302,11 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
                     cand[cnt * 64u] = (uint16_t)(i + j);
                     cnt++;
                 }
+                MRT_STAMP(2);
             }
+            // the last prefetch is never consumed, but its destination SGPRs must stay reserved
+            // until it has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi));
             for (uint32_t k = 0; k < cnt; k++) {                        // exact pass, index order
                 const uint32_t idx = cand[k * 64u];
                 exact_test(spheres[idx], idx, o, d, a, t_sup, best);
@@ -240,6 +315,7 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
                 for (uint32_t idx = 0; idx < P.n_spheres; idx++)
                     exact_test(spheres[idx], idx, o, d, a, t_sup, best);
             }
+            MRT_STAMP(3);
 
             if (best < 0) {
                 // color_sky, shader.wgsl:331-334, 343-345
@@ -310,6 +386,7 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
             }
         }
 
+        MRT_STAMP(4);
         if (path_done) {
             color = color + contrib;                                    // :381
             if (started < spp) need_sample = true; else active = false;
@@ -334,16 +411,23 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
 
     if (COUNT) {
         unsigned long long c0 = started, c1 = bounces, c2 = rng.draws;
+        uint32_t t = trips;                       // the wave ran max-over-lanes trips of its loop
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             c0 += __shfl_xor(c0, off);
             c1 += __shfl_xor(c1, off);
             c2 += __shfl_xor(c2, off);
+            const uint32_t o2 = __shfl_xor(t, off);
+            t = t > o2 ? t : o2;
         }
         if (lane == 0 && P.counters) {
             atomicAdd(P.counters + 0, c0);
             atomicAdd(P.counters + 1, c1);
             atomicAdd(P.counters + 2, c2);
+            atomicAdd(P.counters + 3, 64ull * t);
+#ifdef MRT_STAMPS
+            for (int k = 0; k < 6; k++) atomicAdd(P.counters + 4 + k, (unsigned long long)phase_[k]);
+#endif
         }
     }
 }

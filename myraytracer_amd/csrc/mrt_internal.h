@@ -33,7 +33,7 @@ struct KParams {
     const uint32_t* seeds;      // r_rands: local_rows x W x [u32;4]
     const float* prev;          // r_framebuffer: local_rows x W x rgba
     float* out;                 // render target
-    unsigned long long* counters;  // 3 x u64 (mrt_counters) or null
+    unsigned long long* counters;  // 4 x u64 (mrt_counters) or null
 };
 
 // host-callable launchers (kernels.hip)

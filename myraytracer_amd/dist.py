@@ -1,0 +1,78 @@
+"""Multi-GPU tile sharding of the render path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+The reference is single-device; sharding is this build's addition.  Pixels
+are independent (own RNG stream keyed by global pixel index, own output texel; the scene is
+replicated), so the only exchange is ONE gather of the RGBA32F bands to the root at the end
+of a frame.  Bands of 8 rows are dealt round-robin (band b -> rank b % world) because cost
+per row is very uneven (sky rows end at bounce 0).  Each of the 7 peers has its own xGMI
+link to the root, so a direct gather (grouped send/recv) uses all links at once; there is
+nothing to reduce, hence no ring collective.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+BAND_ROWS = 8     # mrt::kBandRows
+
+
+def band_layout(height: int, world: int) -> Tuple[int, int]:
+    """(total bands, bands per rank); every rank holds the same count (the tail is padding)."""
+    nb = (height + BAND_ROWS - 1) // BAND_ROWS
+    return nb, (nb + world - 1) // world
+
+
+def local_rows(height: int, world: int) -> int:
+    return band_layout(height, world)[1] * BAND_ROWS
+
+
+def global_row(local_row: int, rank: int, world: int) -> int:
+    """Inverse of the packing documented at mrt_shard_info."""
+    return ((local_row // BAND_ROWS) * world + rank) * BAND_ROWS + local_row % BAND_ROWS
+
+
+def unshard(gathered: torch.Tensor, height: int) -> torch.Tensor:
+    """gathered: [world, local_rows, W, 4] (rank-major) -> [height, W, 4], row 0 = bottom."""
+    world, lrows, width, ch = gathered.shape
+    nbl = lrows // BAND_ROWS
+    full = gathered.reshape(world, nbl, BAND_ROWS, width, ch).permute(1, 0, 2, 3, 4)
+    return full.reshape(nbl * world * BAND_ROWS, width, ch)[:height].contiguous()
+
+
+def gather_framebuffer(local: torch.Tensor, height: int, dst: int = 0,
+                       out: Optional[torch.Tensor] = None, group=None) -> Optional[torch.Tensor]:
+    """Gather every rank's packed bands to `dst` and un-permute them into the full image.
+
+    local: [local_rows, W, 4] f32 on this rank's device.  `out` (dst only) may be a
+    preallocated [world, local_rows, W, 4] staging tensor.  Returns the image on dst, None elsewhere.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return unshard(local.unsqueeze(0), height)
+    rank = dist.get_rank(group)
+    if rank == dst:
+        if out is None:
+            out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.gather(local, list(out.unbind(0)), dst=dst, group=group)
+        return unshard(out, height)
+    dist.gather(local, None, dst=dst, group=group)
+    return None
+
+
+class _DevicePtr:
+    """Wraps a raw device pointer owned by an mrt_ctx as a __cuda_array_interface__ object."""
+
+    def __init__(self, ptr: int, shape, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+def framebuffer_tensor(state, device: Optional[torch.device] = None) -> torch.Tensor:
+    """Zero-copy torch view of the State's most recent framebuffer ([local_rows, W, 4] f32)."""
+    _, _, rows, width = state.shard_info()
+    ptr = state.framebuffer_device_ptr()
+    if not ptr:
+        raise RuntimeError("no framebuffer")
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.as_tensor(_DevicePtr(ptr, (rows, width, 4)), device=dev)

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Dev helper (GPU box): phase shares of the bounce loop from the -DMRT_STAMPS build.
+   MRT_LIB_OVERRIDE=myraytracer_amd/lib/libmyraytracer_amd_stamps.so python scripts/phase_profile.py"""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import myraytracer_amd as M
+from myraytracer_amd import _lib
+a = sys.argv[1:]
+scene = a[0] if a else "cover-glass"
+w, h, spp = (int(a[1]), int(a[2]), int(a[3])) if len(a) > 3 else (1920, 1080, 32)
+sp, cam = M.scene_cover(1, scene == "cover-glass") if scene.startswith("cover") else (M.scene_default(), None)
+with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
+    st.set_world(sp)
+    if cam is not None: st.set_camera(cam)
+    st.render(1); st.sync()
+    raw = (C.c_uint64 * 16)()
+    _lib.load().mrt_debug_read_counters(st._ctx, raw)
+    names = ["new_sample", "sweep", "push", "exact", "shade", "tail"]
+    ph = [raw[4 + k] for k in range(6)]
+    tot = sum(ph)
+    print("kernel ms", st.last_kernel_ms(), "wave sweeps", raw[3] / 64)
+    for n, v in zip(names, ph):
+        print(f"{n:12s} {v / max(1, tot):7.3%}  cycles/wave-iteration {v / (raw[3] / 64):9.1f}")

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Dev helper (GPU box): render one frame and print kernel time + counters."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import myraytracer_amd as M
+
+def run(scene, w, h, spp, depth=50, frames=2):
+    if scene == "cover-glass": sp, cam = M.scene_cover(1, True)
+    elif scene == "cover": sp, cam = M.scene_cover(1, False)
+    elif scene == "stress": sp, cam = M.scene_stress(1, 100)
+    else: sp, cam = M.scene_default(), None
+    with M.State(M.Args(w, h, spp, depth, 1.0), seed=1) as st:
+        st.set_world(sp)
+        if cam is not None: st.set_camera(cam)
+        st.render(1); st.sync()
+        c0 = st.read_counters()
+        st.render(frames - 1); st.sync()
+        c1 = st.read_counters()
+        ms = st.kernel_ms_history(frames)[1:]
+        d = {k: (c1[k] - c0[k]) / (frames - 1) for k in c0}
+        n = len(sp)
+        ms_avg = sum(ms) / len(ms)
+        tests = d["world_hit_calls"] * n
+        print(json.dumps({"scene": scene, "n": n, "w": w, "h": h, "spp": spp, "ms": round(ms_avg, 3),
+                          "Msamples/s": round(w * h * spp / ms_avg * 1e-3, 1),
+                          "bounces/sample": round(d["world_hit_calls"] / d["samples"], 3),
+                          "lane_util": round(d["world_hit_calls"] / max(1, d["lane_slots"]), 4),
+                          "Gtests/s": round(tests / ms_avg * 1e-6, 1),
+                          "wave_sweeps": d["lane_slots"] / 64}))
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    run(a[0] if a else "cover-glass", int(a[1]) if len(a) > 1 else 1920, int(a[2]) if len(a) > 2 else 1080,
+        int(a[3]) if len(a) > 3 else 32, int(a[4]) if len(a) > 4 else 50)
