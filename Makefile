@@ -10,7 +10,7 @@ CLI      := $(LIBDIR)/native_runner
 # -fno-vectorize -fno-slp-vectorize: v_pk_* fp32 is not faster than scalar VALU on gfx950
 # and SLP packing spends s_mov on SGPR pairs (profiles/r01_ubench_sphere_loop_*.txt).
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-vectorize -fno-slp-vectorize -Wall -Wextra -Wno-unused-parameter
-SRCS     := $(CSRC)/kernels.hip $(CSRC)/api.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
+SRCS     := $(CSRC)/kernels.hip $(CSRC)/tile_order.hip $(CSRC)/api.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
 HDRS     := $(CSRC)/mrt_internal.h include/myraytracer_amd.h
 
 all: $(LIB) $(CLI) oracle

@@ -63,15 +63,11 @@ def cpu_baseline(spheres, cam, width, height, depth, seed, budget_s=15.0):
     packed = O.pack_world(to_oracle_spheres(O, spheres))
     ocam = to_oracle_camera(O, cam)
     seeds = O.fill_seeds(seed, width, height)
-    # calibrate on every 16th row at 1 spp, then size the sample to ~budget_s
+    # calibrate with one full 1-spp frame, then size the timed sample to ~budget_s
     t0 = time.perf_counter()
-    cal_rows = 0
-    for y in range(0, height, 16):
-        O.render_frame(width, height, 1, depth, packed, ocam, seeds, rows=(y, y + 1), nthreads=cores)
-        cal_rows += 1
+    O.render_frame(width, height, 1, depth, packed, ocam, seeds, nthreads=cores)
     cal = time.perf_counter() - t0
-    rate = cal_rows * width / cal                       # samples/s (1 row at a time under-uses the cores: lower bound)
-    spp = max(1, min(64, int(budget_s * rate / (width * height))))
+    spp = max(1, min(256, int(budget_s / cal)))
     t0 = time.perf_counter()
     O.render_frame(width, height, spp, depth, packed, ocam, seeds, nthreads=cores)
     dt = time.perf_counter() - t0
@@ -162,13 +158,13 @@ def main():
 
     # whole-job numbers: max time over ranks, summed counters
     stats = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=device)
-    sums = torch.tensor([c1["world_hit_calls"] - c0["world_hit_calls"], c1["samples"] - c0["samples"]],
-                        dtype=torch.float64, device=device)
+    sums = torch.tensor([c1["world_hit_calls"] - c0["world_hit_calls"], c1["samples"] - c0["samples"],
+                         c1["lane_slots"] - c0["lane_slots"]], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     elapsed_max, kernel_ms_max = float(stats[0]), float(stats[1])
-    hits, samples_counted = float(sums[0]), float(sums[1])
+    hits, samples_counted, lane_slots = float(sums[0]), float(sums[1]), float(sums[2])
 
     if rank == 0:
         total_samples = float(width) * height * spp * a.steps
@@ -204,6 +200,7 @@ def main():
             "valu": {"note": "the binding resource: fp32 VALU issue of the ray-sphere discriminant sweep",
                      "sphere_tests_per_launch": tests_per_launch,
                      "mean_bounces_per_sample": hits / total_samples if total_samples else None,
+                     "lane_utilisation": hits / lane_slots if lane_slots else None,
                      "achieved_tflops": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12, "peak_tflops": FP32_PEAK_TFLOPS,
                      "frac": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12 / FP32_PEAK_TFLOPS,
                      "issue_frac": tests_per_launch * VALU_PER_TEST / kernel_s / LANE_OPS_PEAK},

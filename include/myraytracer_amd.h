@@ -209,6 +209,11 @@ int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since c
 /* Diagnostic: the 16 raw u64 counter slots (0..3 = mrt_counters; 4.. are phase cycle sums
  * written only by the -DMRT_STAMPS profiling build). */
 int mrt_debug_read_counters(mrt_ctx* ctx, uint64_t out[16]);
+/* Diagnostic A/B switch: 0 launches tiles in row-major order instead of heaviest-first. */
+int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);
+/* Diagnostic: per-wave log {t_start, t_end (100 MHz ticks), loop trips, bounces}, 4 u64 per 8x8
+ * tile, written only by the -DMRT_STAMPS build.  out == NULL allocates the log. */
+int mrt_debug_wave_log(mrt_ctx* ctx, uint64_t* out, size_t cap_waves, size_t* n_waves);
 /* Elapsed GPU time (ms) of the most recent redraw's render kernel, from HIP events on
  * the launch stream.  Synchronises on the stop event. */
 int mrt_last_kernel_ms(mrt_ctx* ctx, float* ms);

@@ -53,6 +53,15 @@ struct mrt_ctx {
     float* d_fb[2] = {nullptr, nullptr};   // [target, secondary] ping-pong (lib.rs:505-543)
     int target = 0;                        // index of the buffer the NEXT redraw writes
     unsigned long long* d_counters = nullptr;
+    // launch order (tile_order.hip): costs written by frame n order the launch of frame n+1
+    uint32_t* d_tile_cost = nullptr;
+    uint32_t* d_tile_order = nullptr;
+    uint32_t* d_sort_scratch = nullptr;
+    uint32_t tiles_x = 0, n_tiles = 0;
+    bool cost_valid = false;
+    bool lpt_enabled = true;
+    unsigned long long* d_wave_log = nullptr;   // diagnostic, see mrt_debug_wave_log
+    size_t wave_log_waves = 0;
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -93,7 +102,12 @@ void free_frame_buffers(mrt_ctx* c) {
     if (c->d_seeds) (void)hipFree(c->d_seeds);
     if (c->d_fb[0]) (void)hipFree(c->d_fb[0]);
     if (c->d_fb[1]) (void)hipFree(c->d_fb[1]);
+    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
+    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
+    if (c->d_sort_scratch) (void)hipFree(c->d_sort_scratch);
     c->d_seeds = nullptr; c->d_fb[0] = c->d_fb[1] = nullptr;
+    c->d_tile_cost = c->d_tile_order = c->d_sort_scratch = nullptr;
+    c->cost_valid = false;
 }
 
 void free_world(mrt_ctx* c) {
@@ -116,6 +130,11 @@ int alloc_frame_buffers(mrt_ctx* c) {
     HIP_TRY(c, hipMalloc(&c->d_fb[1], n * 4 * sizeof(float)));
     HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, n * 4 * sizeof(float), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, n * 4 * sizeof(float), c->stream));
+    c->tiles_x = (c->args.width + mrt::kTileW - 1) / mrt::kTileW;
+    c->n_tiles = c->tiles_x * c->local_bands;
+    HIP_TRY(c, hipMalloc(&c->d_tile_cost, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_tile_order, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_sort_scratch, 1024 * sizeof(uint32_t)));
     int e = mrt::launch_fill_seeds(c->d_seeds, c->seed, c->args.width, c->args.height, c->shard_rank,
                                    c->shard_world, c->local_bands, c->stream);
     if (e) return fail(c, MRT_ERR_HIP, "fill_seeds launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -332,6 +351,7 @@ void mrt_destroy(mrt_ctx* c) {
     free_frame_buffers(c);
     free_world(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_wave_log) (void)hipFree(c->d_wave_log);
     for (uint32_t i = 0; i < mrt_ctx::kEventRing; i++) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -411,6 +431,7 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     HIP_TRY(c, upload((void**)&c->d_vec4, vec4, n_vec4 * 4 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
+    c->cost_valid = false;
     c->world = *w;
     c->n_spheres = (uint32_t)n;
     c->n_padded = n_padded;
@@ -435,6 +456,7 @@ int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
     int st = mrt_camera_derive(cam, &raw);
     if (st != MRT_OK) return fail(c, st, "mrt_set_camera: degenerate or invalid camera");
     c->camera = *cam; c->cam_raw = raw;
+    c->cost_valid = false;
     return MRT_OK;
 }
 
@@ -502,12 +524,32 @@ int mrt_redraw(mrt_ctx* c) {
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
     p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
     p.counters = c->d_counters;
+    p.wave_log = c->d_wave_log;
+    p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
+    p.tile_cost = c->d_tile_cost;
+    p.tile_order = nullptr;
+    // Launch order: heaviest tile first, from the previous frame's per-tile cost; before the
+    // first frame of a scene a 1-spp pilot pass (no output) provides the estimate when the
+    // frame is long enough to pay for it.
+    if (c->lpt_enabled) {
+        if (!c->cost_valid && c->locals.samples_per_frame >= 16u) {
+            int pe = mrt::launch_render(p, true, c->stream);
+            if (pe) return fail(c, MRT_ERR_HIP, "pilot launch failed: %s", hipGetErrorString((hipError_t)pe));
+            c->cost_valid = true;
+        }
+        if (c->cost_valid) {
+            int se = mrt::launch_sort_tiles(c->d_tile_cost, c->d_tile_order, c->d_sort_scratch, c->n_tiles, c->stream);
+            if (se) return fail(c, MRT_ERR_HIP, "tile sort launch failed: %s", hipGetErrorString((hipError_t)se));
+            p.tile_order = c->d_tile_order;
+        }
+    }
     const uint32_t slot = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
     HIP_TRY(c, hipEventRecord(c->ev_start[slot], c->stream));
-    int e = mrt::launch_render(p, c->local_bands, c->stream);
+    int e = mrt::launch_render(p, false, c->stream);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
     HIP_TRY(c, hipEventRecord(c->ev_stop[slot], c->stream));
     c->timed_frames++;
+    c->cost_valid = true;
 
     c->target ^= 1;                                                       // framebuffers.swap(), lib.rs:299
     if (c->frames_done != UINT32_MAX) c->frames_done++;                   // saturating_add, lib.rs:300
@@ -522,6 +564,13 @@ int mrt_render(mrt_ctx* c, uint32_t frames) {
         int st = mrt_redraw(c);
         if (st != MRT_OK) return st;
     }
+    return MRT_OK;
+}
+
+// diagnostic / A-B switch: 0 = launch tiles in row-major order
+int mrt_debug_set_tile_sort(mrt_ctx* c, int enabled) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    c->lpt_enabled = enabled != 0;
     return MRT_OK;
 }
 
@@ -604,6 +653,29 @@ int mrt_debug_read_counters(mrt_ctx* c, uint64_t out[16]) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(out, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MRT_OK;
+}
+
+// diagnostic: enable / read the per-wave log {t_start, t_end (100 MHz ticks), trips, bounces}
+// that -DMRT_STAMPS builds write; out == NULL just (re)allocates it for the current shard.
+int mrt_debug_wave_log(mrt_ctx* c, uint64_t* out, size_t cap_waves, size_t* n_waves) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = c->n_tiles;
+    if (n_waves) *n_waves = n;
+    if (!c->d_wave_log || c->wave_log_waves != n) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_wave_log) (void)hipFree(c->d_wave_log);
+        c->d_wave_log = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_wave_log, n * 4 * sizeof(uint64_t)));
+        HIP_TRY(c, hipMemset(c->d_wave_log, 0, n * 4 * sizeof(uint64_t)));
+        c->wave_log_waves = n;
+    }
+    if (out) {
+        if (cap_waves < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_wave_log: need %zu waves", n);
+        HIP_TRY(c, hipMemcpyAsync(out, c->d_wave_log, n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return MRT_OK;
 }
 

@@ -152,8 +152,8 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 d, float a, uint32
     test4(g.hi, o, d, a, bits);
 }
 
-// Candidate list: per wave kCandCap entries x 64 lanes of u16, entry-major so that the 64
-// lanes of one push / pop touch 128 consecutive bytes.
+// Candidate masks: per wave kBlockChunks x 64 lanes of u16 (one 16-sphere sign mask per chunk
+// and lane), chunk-major so that the 64 lanes of one access touch 128 consecutive bytes.
 // Diagnostic build only (-DMRT_STAMPS, scripts/phase_profile.sh): s_memtime shares of the
 // phases of the bounce loop, summed per wave into counters[4..].  Never in the product .so.
 #ifdef MRT_STAMPS
@@ -169,25 +169,30 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 d, float a, uint32
 #define MRT_STAMP(k) do { } while (0)
 #endif
 
-constexpr uint32_t kCandCap = 64;
-constexpr uint32_t kWavesPerBlock = 4;
+constexpr uint32_t kBlockChunks = 32;     // 32 chunks x 16 spheres = 512 spheres between exact passes
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256) render_kernel(const KParams P) {
-    __shared__ uint16_t cand_lds[kWavesPerBlock * kCandCap * 64];
+template <bool COUNT, bool PILOT>
+// One wave per workgroup: a finished wave frees its slot at once (with 4-wave workgroups
+// the LDS and the launch slot were held until the slowest of the four waves ended).
+__global__ void __launch_bounds__(64) render_kernel(const KParams P) {
+    __shared__ uint16_t mask_lds[kBlockChunks * 64];
 
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint16_t* const cand = cand_lds + wave * (kCandCap * 64u) + lane;   // entry k at cand[k*64]
+    const uint32_t lane = threadIdx.x;
+    uint16_t* const masks = mask_lds + lane;   // chunk c at masks[c*64]
 
     const uint32_t W = P.locals.shape[0], H = P.locals.shape[1];
-    const uint32_t px = blockIdx.x * kTileW + wave * 8u + (lane & 7u);
-    const uint32_t lrow = blockIdx.y * kBandRows + (lane >> 3);                       // row in this shard
-    const uint32_t py = (blockIdx.y * P.shard_world + P.shard_rank) * kBandRows + (lane >> 3);  // global row, 0 = bottom
+    // Launch order is heaviest tile first (longest-processing-time scheduling, tile_order.hip):
+    // with only ~4.5 waves per wave slot at 1920x1080 the heaviest tiles would otherwise start
+    // late and run on an emptying chip for the last fifth of the kernel.
+    const uint32_t tile = P.tile_order ? P.tile_order[blockIdx.x] : blockIdx.x;
+    const uint32_t tile_x = tile % P.tiles_x, band = tile / P.tiles_x;
+    const uint32_t px = tile_x * kTileW + (lane & 7u);
+    const uint32_t lrow = band * kBandRows + (lane >> 3);                             // row in this shard
+    const uint32_t py = (band * P.shard_world + P.shard_rank) * kBandRows + (lane >> 3);  // global row, 0 = bottom
     const bool valid = (px < W) && (py < H);
     const size_t texel = (size_t)lrow * W + px;
 
-    const uint32_t spp = P.locals.samples_per_frame;
+    const uint32_t spp = PILOT ? 1u : P.locals.samples_per_frame;   // pilot: 1 spp, cost estimate only
     const uint32_t n_padded = P.n_padded;
     const SphereRec* __restrict__ spheres = P.spheres;
     const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.spheres;
@@ -216,6 +221,7 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
 #ifdef MRT_STAMPS
     uint64_t phase_[6] = {0, 0, 0, 0, 0, 0};
     uint64_t last_ = __builtin_amdgcn_s_memtime();
+    const uint64_t wave_t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
 
     while (active) {
@@ -272,45 +278,47 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
             // reference treats as "not < 0".  Such lanes take the literal loop below.
             const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
                                  __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff());
-            uint32_t cnt = 0;
-            // Discriminant sweep.  Sphere records are wave-uniform: they are fetched with scalar
-            // loads, 8 records (two s_load_dwordx16 = 32 SGPRs) per group, double-buffered:
-            // wait for group g, issue the loads of group g+1, then run the 8 x 12 VALU ops of
-            // group g while they fly.
+            // Discriminant sweep + exact pass, in blocks of kBlockChunks x kChunk spheres.
+            // Sphere records are wave-uniform: they are fetched with scalar loads, 8 records (two
+            // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
+            // loads of group g+1, then run the 8 x 12 VALU ops of group g while they fly.
             Sph8 ga, gb;
             smem_load8(ga, sph_quads, 0u);
-            for (uint32_t i = 0; i < n_padded; i += kChunk) {
-                uint32_t bits = 0;
-                smem_wait_then_load8(ga, gb, sph_quads, i + 8u, bits);  test8(ga, o, d, a, bits);
-                smem_wait_then_load8(gb, ga, sph_quads, i + 16u, bits); test8(gb, o, d, a, bits);
-                smem_wait_then_load8(ga, gb, sph_quads, i + 24u, bits); test8(ga, o, d, a, bits);
-                const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
-                smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);     test8(gb, o, d, a, bits);
-                MRT_STAMP(1);
-                uint32_t m = weird ? 0u : ~bits;                        // 1 = discriminant >= 0
-                // flush before the list could overflow (never for ordinary scenes)
-                if (cnt + kChunk > kCandCap) {
-                    for (uint32_t k = 0; k < cnt; k++) {
-                        const uint32_t idx = cand[k * 64u];
-                        exact_test(spheres[idx], idx, o, d, a, t_sup, best);
+            for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
+                const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
+                uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
+                uint32_t c = 0;
+                for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
+                    uint32_t bits = 0;
+                    smem_wait_then_load8(ga, gb, sph_quads, i + 8u, bits);  test8(ga, o, d, a, bits);
+                    const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
+                    smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);     test8(gb, o, d, a, bits);
+                    MRT_STAMP(1);
+                    // 16 signs in bits[15:0], sphere i at bit 15; candidate = discriminant >= 0
+                    const uint32_t m = weird ? 0u : (~bits & 0xFFFFu);
+                    masks[c * 64u] = (uint16_t)m;
+                    nz |= (m != 0u ? 1u : 0u) << c;
+                    MRT_STAMP(2);
+                }
+                // exact pass over this block's candidates, each lane in increasing sphere index:
+                // every trip handles one candidate of every lane that still has one
+                uint32_t m = 0, base = 0;
+                while ((nz | m) != 0u) {
+                    if (m == 0u) {
+                        const uint32_t cc = (uint32_t)__builtin_ctz(nz);
+                        nz &= nz - 1u;
+                        m = masks[cc * 64u];
+                        base = blk + cc * kChunk;
                     }
-                    cnt = 0;
+                    const uint32_t j = (uint32_t)__builtin_clz(m) - 16u;   // sphere base + j, lowest index first
+                    m &= ~(0x8000u >> j);
+                    const uint32_t idx = base + j;
+                    exact_test(spheres[idx], idx, o, d, a, t_sup, best);
                 }
-                while (m != 0u) {
-                    const uint32_t j = (uint32_t)__builtin_clz(m);      // lowest sphere index first
-                    m &= ~(0x80000000u >> j);
-                    cand[cnt * 64u] = (uint16_t)(i + j);
-                    cnt++;
-                }
-                MRT_STAMP(2);
             }
             // the last prefetch is never consumed, but its destination SGPRs must stay reserved
             // until it has landed
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi));
-            for (uint32_t k = 0; k < cnt; k++) {                        // exact pass, index order
-                const uint32_t idx = cand[k * 64u];
-                exact_test(spheres[idx], idx, o, d, a, t_sup, best);
-            }
             if (weird) {
                 for (uint32_t idx = 0; idx < P.n_spheres; idx++)
                     exact_test(spheres[idx], idx, o, d, a, t_sup, best);
@@ -393,7 +401,7 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
         }
     }
 
-    if (valid) {
+    if (!PILOT && valid) {
         const float n = (float)spp;
         color = v3(color.x / n, color.y / n, color.z / n);              // :383
         const float w = P.locals.framebuffer_weight;
@@ -404,21 +412,26 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
         r.z = mixf(color.z, q.z, w);
         r.w = mixf(1.0f, q.w, w);
         reinterpret_cast<float4*>(P.out)[texel] = r;
-    } else if (px < W) {
+    } else if (!PILOT && px < W) {
         // padding rows of the last band of a shard: keep them defined
         reinterpret_cast<float4*>(P.out)[texel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 
-    if (COUNT) {
+    uint32_t t = trips;                           // the wave ran max-over-lanes trips of its loop
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o2 = __shfl_xor(t, off);
+        t = t > o2 ? t : o2;
+    }
+    if (lane == 0 && P.tile_cost) P.tile_cost[tile] = t;   // next frame's launch order
+
+    if (COUNT && !PILOT) {
         unsigned long long c0 = started, c1 = bounces, c2 = rng.draws;
-        uint32_t t = trips;                       // the wave ran max-over-lanes trips of its loop
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             c0 += __shfl_xor(c0, off);
             c1 += __shfl_xor(c1, off);
             c2 += __shfl_xor(c2, off);
-            const uint32_t o2 = __shfl_xor(t, off);
-            t = t > o2 ? t : o2;
         }
         if (lane == 0 && P.counters) {
             atomicAdd(P.counters + 0, c0);
@@ -427,6 +440,10 @@ __global__ void __launch_bounds__(256) render_kernel(const KParams P) {
             atomicAdd(P.counters + 3, 64ull * t);
 #ifdef MRT_STAMPS
             for (int k = 0; k < 6; k++) atomicAdd(P.counters + 4 + k, (unsigned long long)phase_[k]);
+            if (P.wave_log) {
+                unsigned long long* w = P.wave_log + 4ull * tile;
+                w[0] = wave_t0_; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = t; w[3] = c1;
+            }
 #endif
         }
     }
@@ -461,14 +478,15 @@ __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64
 
 }  // namespace
 
-int launch_render(const KParams& p, uint32_t local_bands, void* stream) {
-    const uint32_t W = p.locals.shape[0];
-    if (W == 0 || local_bands == 0) return 0;
-    dim3 grid((W + kTileW - 1) / kTileW, local_bands), block(256);
-    if (p.counters)
-        hipLaunchKernelGGL(render_kernel<true>, grid, block, 0, (hipStream_t)stream, p);
+int launch_render(const KParams& p, bool pilot, void* stream) {
+    if (p.n_tiles == 0) return 0;
+    dim3 grid(p.n_tiles), block(64);
+    if (pilot)
+        hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (p.counters)
+        hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(render_kernel<false>, grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

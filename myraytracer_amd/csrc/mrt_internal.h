@@ -7,9 +7,9 @@
 namespace mrt {
 
 constexpr uint32_t kBandRows = 8;        // shard granule: 8 image rows (one row of 8x8 wave tiles)
-constexpr uint32_t kTileW = 32;          // a 256-thread workgroup covers 32x8 pixels = 4 wave tiles
-constexpr uint32_t kChunk = 32;          // spheres per unrolled chunk of the discriminant loop
-constexpr uint32_t kMaxSpheres = 65535;  // candidate indices are stored as u16 in LDS
+constexpr uint32_t kTileW = 8;           // one 64-lane wave (= one workgroup) covers an 8x8 pixel tile
+constexpr uint32_t kChunk = 16;          // spheres per chunk of the discriminant sweep (one u16 sign mask)
+constexpr uint32_t kMaxSpheres = 1u << 20;
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
 // the host from the reference's SoA arrays (centres: vec4_f32_data, radii: f32_data;
@@ -34,10 +34,17 @@ struct KParams {
     const float* prev;          // r_framebuffer: local_rows x W x rgba
     float* out;                 // render target
     unsigned long long* counters;  // 4 x u64 (mrt_counters) or null
+    const uint32_t* tile_order; // n_tiles tile ids, heaviest first, or null = identity
+    uint32_t* tile_cost;        // n_tiles: loop trips of each tile's wave in this frame, or null
+    uint32_t tiles_x, n_tiles;  // tiles per band row; tiles in this shard (= grid size)
+    unsigned long long* wave_log;  // diagnostic (-DMRT_STAMPS builds): 4 x u64 per wave, or null
 };
 
 // host-callable launchers (kernels.hip)
-int launch_render(const KParams& p, uint32_t local_bands, void* stream);
+int launch_render(const KParams& p, bool pilot, void* stream);
+// tile_order.hip: order[] = tile ids sorted by cost[] descending (bucket sort; ties in any order).
+// scratch: 1024 u32.
+int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, uint32_t n_tiles, void* stream);
 int launch_fill_seeds(uint32_t* seeds, uint64_t seed, uint32_t width, uint32_t height,
                       uint32_t shard_rank, uint32_t shard_world, uint32_t local_bands, void* stream);
 

@@ -1,0 +1,67 @@
+// Launch-order kernels: sort this shard's 8x8 tiles by the cost (bounce-loop trips) their
+// waves had in the previous frame -- or in a 1-spp pilot pass before the first frame --
+// heaviest first.  No reference counterpart: the reference issues one full-screen draw
+// (raytracer/src/lib.rs:262-267) and leaves scheduling to the GPU.  The order only affects
+// WHEN a tile runs, never its pixels (every pixel owns its RNG stream and output texel).
+//
+// A bucket sort is enough (ties may land in any order): key = 5-bit exponent | 5-bit
+// mantissa of the cost, 1024 buckets, three tiny launches.
+
+#include <hip/hip_runtime.h>
+#include "mrt_internal.h"
+
+namespace mrt {
+namespace {
+
+constexpr uint32_t kBuckets = 1024;
+
+// monotonic in cost; bucket 1023 = heaviest
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t cost) {
+    if (cost < 32u) return cost;                       // exact for tiny costs
+    const uint32_t e = 31u - (uint32_t)__builtin_clz(cost);   // 5..31
+    const uint32_t m = (cost >> (e - 5u)) & 31u;              // 5 bits below the leading one
+    const uint32_t key = (e - 4u) * 32u + m;                  // 32.. 895
+    return key < kBuckets ? key : kBuckets - 1u;
+}
+
+__global__ void __launch_bounds__(256) tile_hist_kernel(const uint32_t* __restrict__ cost, uint32_t* hist, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+}
+
+// one block of 1024 threads: hist[b] <- number of tiles in heavier buckets (descending exclusive scan)
+__global__ void __launch_bounds__(1024) tile_scan_kernel(uint32_t* hist) {
+    __shared__ uint32_t s[kBuckets];
+    const uint32_t t = threadIdx.x;
+    s[t] = hist[kBuckets - 1u - t];                    // reversed: index 0 = heaviest bucket
+    __syncthreads();
+    for (uint32_t off = 1; off < kBuckets; off <<= 1) {
+        const uint32_t v = (t >= off) ? s[t - off] : 0u;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    hist[kBuckets - 1u - t] = (t == 0) ? 0u : s[t - 1u];
+}
+
+__global__ void __launch_bounds__(256) tile_scatter_kernel(const uint32_t* __restrict__ cost, uint32_t* offsets,
+                                                           uint32_t* __restrict__ order, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[atomicAdd(&offsets[cost_bucket(cost[i])], 1u)] = i;
+}
+
+}  // namespace
+
+int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, uint32_t n_tiles, void* stream) {
+    if (n_tiles == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, kBuckets * sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    const uint32_t blocks = (n_tiles + 255u) / 256u;
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(blocks), dim3(256), 0, st, cost, scratch, n_tiles);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, scratch);
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, st, cost, scratch, order, n_tiles);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mrt

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Dev helper (GPU box, -DMRT_STAMPS build): how many waves are resident over the kernel's lifetime."""
+import ctypes as C, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import myraytracer_amd as M
+from myraytracer_amd import _lib
+a = sys.argv[1:]
+w, h, spp = (int(a[0]), int(a[1]), int(a[2])) if len(a) > 2 else (1920, 1080, 32)
+sp, cam = M.scene_cover(1, True)
+L = _lib.load()
+with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
+    st.set_world(sp); st.set_camera(cam)
+    n = C.c_size_t()
+    L.mrt_debug_wave_log(st._ctx, None, 0, C.byref(n))
+    st.render(1); st.sync()
+    log = np.zeros((n.value, 4), np.uint64)
+    L.mrt_debug_wave_log(st._ctx, log.ctypes.data, n.value, C.byref(n))
+    t0, t1, trips = log[:, 0].astype(np.int64), log[:, 1].astype(np.int64), log[:, 2]
+    start = t0.min(); t0 -= start; t1 -= start
+    total = t1.max()
+    print("kernel ms", st.last_kernel_ms(), "span ticks", total, "waves", len(log))
+    edges = np.linspace(0, total, 21)
+    for i in range(20):
+        mid = 0.5 * (edges[i] + edges[i + 1])
+        resident = int(((t0 <= mid) & (t1 > mid)).sum())
+        print(f"{i*5:3d}%  resident waves {resident:6d}")
+    dur = (t1 - t0)
+    print("wave duration ticks: mean %.0f  p50 %.0f  p99 %.0f  max %.0f" % (dur.mean(), np.percentile(dur, 50), np.percentile(dur, 99), dur.max()))
+    late = np.argsort(t1)[-10:]
+    tw = (w + 7) // 8
+    for i in late:
+        print("late tile x=%d band=%d trips=%d start=%.2f end=%.2f" % (i % tw, i // tw, trips[i], t0[i] / total, t1[i] / total))
