@@ -1,0 +1,65 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/myraytracer_amd.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "myraytracer_amd.h")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(mrt):
+    from myraytracer_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    declared = header_functions()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in the header but not exported by the .so"
+    assert sorted(_lib.EXPORTS) == declared, "python binding list and header disagree"
+
+
+def test_abi_version_and_status_strings(mrt):
+    from myraytracer_amd import _lib
+    L = _lib.load()
+    assert L.mrt_abi_version() == 1
+    assert L.mrt_status_string(0) == b"ok"
+    assert L.mrt_status_string(2) == b"no usable HIP device"
+    assert L.mrt_last_error(None) is not None
+
+
+def test_struct_sizes_match_reference_layouts(mrt):
+    from myraytracer_amd import _lib
+    assert C.sizeof(_lib.MrtLocals) == 48          # lib.rs:368-377, 16-aligned
+    assert C.sizeof(_lib.MrtWorld) == 80           # raw::World 64 B + DielectricRange 16 B
+    assert C.sizeof(_lib.MrtSphereRange) == 32 and C.sizeof(_lib.MrtLambertianRange) == 16
+    assert C.sizeof(_lib.MrtMetalRange) == 16 and C.sizeof(_lib.MrtDielectricRange) == 16
+    assert C.sizeof(_lib.MrtArgs) == 20 and C.sizeof(_lib.MrtSphere) == 36
+    assert _lib.MrtLocals.rng_shuffle.offset == 16 and _lib.MrtLocals.framebuffer_weight.offset == 32
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(mrt):
+    """Without a GPU (this container) mrt_create must fail; on the GPU box this test is a no-op."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mrt.MrtError) as e:
+        mrt.State(mrt.Args(16, 16))
+    assert e.value.status == 2
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under myraytracer_amd/ or include/ may reference it."""
+    for base in ("myraytracer_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "rt_oracle" not in text and "pyoracle" not in text, os.path.join(dirpath, f)
+                    assert not re.search(r"#include\s+[\"<].*oracle", text), os.path.join(dirpath, f)

@@ -1,0 +1,205 @@
+"""GPU tests through the C ABI: committed golden fixtures, the raw-World upload path, explicit
+seed textures, sharded rendering, error behaviour, and the diagnostics that must not change
+pixels (tile launch order)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import gpu_render, mismatch_report, oracle_render
+from make_golden_cases import GOLDEN, load_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    return json.load(open(os.path.join(GOLDEN, "golden.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c["name"])
+def test_golden_fixture(mrt, case):
+    raw, cam = load_inputs(case)
+    spheres = raw.view(mrt.SPHERE_DTYPE)
+    camera = None if cam["mode"] == 0 else mrt.Camera(1, cam["lookfrom"], cam["lookat"], cam["vup"], cam["vfov_deg"],
+                                                      cam["defocus_angle_deg"], cam["focus_dist"])
+    got, counters, _ = gpu_render(mrt, spheres, camera, case["width"], case["height"], case["spp"], case["depth"],
+                                  case["seed"], case["frames"], case["max_w"])
+    ref = np.fromfile(os.path.join(GOLDEN, case["file"]), np.float32).reshape(case["height"], case["width"], 4)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    for k in ("samples", "world_hit_calls", "rng_draws"):
+        assert counters[k] == case["counters"][k]
+
+
+def test_raw_world_upload_equals_aos_upload(mrt):
+    """mrt_set_world_raw takes the reference's raw::World + three arrays verbatim (lib.rs:768-863)."""
+    sc, cam = mrt.scene_cover(1, True)
+    w, vec4, f32, i32 = mrt.pack_world(sc)
+    with mrt.State(mrt.Args(64, 40, 2, 20), seed=4) as st:
+        st.set_world_raw(w, vec4, f32, i32)
+        st.set_camera(cam)
+        st.render(1)
+        a = st.read_framebuffer()
+    b, _, _ = gpu_render(mrt, sc, cam, 64, 40, 2, 20, 4)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_raw_world_validation(mrt):
+    sc = mrt.scene_default()
+    w, vec4, f32, i32 = mrt.pack_world(sc)
+    with mrt.State(mrt.Args(16, 16), seed=1) as st:
+        with pytest.raises(mrt.MrtError) as e:
+            st.redraw()                                         # no scene yet
+        assert e.value.status == 4
+        bad = type(w).from_buffer_copy(bytes(w))
+        bad.metals.fuzz_base_idx = 99                           # range outside f32_data
+        with pytest.raises(mrt.MrtError) as e:
+            st.set_world_raw(bad, vec4, f32, i32)
+        assert e.value.status == 5
+        v2 = vec4.copy()
+        v2[1, 0] = np.nan
+        with pytest.raises(mrt.MrtError):
+            st.set_world_raw(w, v2, f32, i32)
+        i2 = i32.copy()
+        i2[w.spheres.material_idx_base_idx + 3] = 5             # metal index out of range
+        with pytest.raises(mrt.MrtError):
+            st.set_world_raw(w, vec4, f32, i2)
+        st.set_world_raw(w, vec4, f32, i32)                     # still usable afterwards
+        st.redraw()
+        assert np.isfinite(st.read_framebuffer()).all()
+
+
+def test_unknown_material_type_absorbs(mrt, oracle):
+    """shader.wgsl:249-251: a material type that is neither 1 nor 2 (nor the extension 3) returns black."""
+    sc = mrt.scene_default()
+    w, vec4, f32, i32 = mrt.pack_world(sc)
+    i32 = i32.copy()
+    i32[w.spheres.material_ty_base_idx + 1] = 9
+    with mrt.State(mrt.Args(48, 27, 4, 8), seed=2) as st:
+        st.set_world_raw(w, vec4, f32, i32)
+        st.redraw()
+        got = st.read_framebuffer()
+    pw = oracle.pack_world(sc.view(oracle.SPHERE_DTYPE))
+    pw.i32[w.spheres.material_ty_base_idx + 1] = 9
+    ref = oracle.render(48, 27, 4, 8, pw, oracle.pinhole_camera(), 2)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_explicit_seed_texture(mrt, oracle):
+    """The seed texture is an input (Rgba32Uint WxH, lib.rs:397-415): any caller-supplied one is honoured."""
+    rng = np.random.default_rng(7)
+    seeds = rng.integers(1, 2 ** 32, size=(27, 48, 4), dtype=np.uint32)
+    sc = mrt.scene_default()
+    with mrt.State(mrt.Args(48, 27, 3, 8), seed=0) as st:
+        st.set_world(sc)
+        st.set_seeds(seeds)
+        assert np.array_equal(st.read_seeds()[:27], seeds)
+        st.redraw()
+        got = st.read_framebuffer()
+    ref = oracle.render_frame(48, 27, 3, 8, oracle.pack_world(sc.view(oracle.SPHERE_DTYPE)), oracle.pinhole_camera(), seeds)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_rng_shuffle_override_and_locals(mrt, oracle):
+    sc = mrt.scene_default()
+    with mrt.State(mrt.Args(32, 18, 2, 8, 0.75), seed=3) as st:
+        st.set_world(sc)
+        L0 = st.locals
+        assert (L0.shape[0], L0.shape[1], L0.samples_per_frame, L0.ray_depth) == (32, 18, 2, 8)
+        assert L0.framebuffer_weight == 0.0 and list(L0.rng_shuffle) == [0, 0, 0, 0]      # lib.rs:419-426
+        st.redraw()
+        L1 = st.locals
+        assert L1.framebuffer_weight == 0.5 and list(L1.rng_shuffle) == mrt.frame_shuffle(3, 1)
+        st.set_rng_shuffle([9, 8, 7, 6])
+        st.redraw()
+        assert st.frames_done == 2 and st.locals.framebuffer_weight == np.float32(2) / np.float32(3)
+        got = st.read_framebuffer()
+    pw = oracle.pack_world(sc.view(oracle.SPHERE_DTYPE))
+    seeds = oracle.fill_seeds(3, 32, 18)
+    f0 = oracle.render_frame(32, 18, 2, 8, pw, oracle.pinhole_camera(), seeds, (0, 0, 0, 0), 0.0)
+    f1 = oracle.render_frame(32, 18, 2, 8, pw, oracle.pinhole_camera(), seeds, (9, 8, 7, 6), 0.5, f0)
+    assert np.array_equal(got.view(np.uint32), f1.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,height", [(2, 45), (3, 64), (8, 100)])
+def test_sharded_render_equals_unsharded(mrt, world, height):
+    """Pixels are keyed by global position, so any band sharding reproduces the 1-GPU image bit for bit."""
+    import torch
+    from myraytracer_amd import dist as mdist
+    sc, cam = mrt.scene_cover(1, True)
+    full, _, _ = gpu_render(mrt, sc, cam, 72, height, 2, 30, 11)
+    parts = []
+    for rank in range(world):
+        part, _, _ = gpu_render(mrt, sc, cam, 72, height, 2, 30, 11, shard=(rank, world))
+        assert part.shape == (mdist.local_rows(height, world), 72, 4)
+        parts.append(torch.from_numpy(part))
+    got = mdist.unshard(torch.stack(parts), height).numpy()
+    assert np.array_equal(got.view(np.uint32), full.view(np.uint32))
+
+
+def test_zero_copy_framebuffer_tensor(mrt):
+    import torch
+    from myraytracer_amd import dist as mdist
+    sc = mrt.scene_default()
+    with mrt.State(mrt.Args(40, 24, 2, 8), seed=1, stream=torch.cuda.current_stream().cuda_stream) as st:
+        st.set_world(sc)
+        st.redraw()
+        t = mdist.framebuffer_tensor(st)
+        torch.cuda.synchronize()
+        assert t.is_cuda and tuple(t.shape) == (24, 40, 4)
+        img = mdist.gather_framebuffer(t, 24)
+        assert np.array_equal(img.cpu().numpy(), st.read_framebuffer())
+
+
+def test_tile_launch_order_does_not_change_pixels(mrt):
+    from myraytracer_amd import _lib
+    sc, cam = mrt.scene_cover(1, True)
+    outs = []
+    for enabled in (1, 0):
+        with mrt.State(mrt.Args(160, 96, 16, 50), seed=5) as st:
+            _lib.load().mrt_debug_set_tile_sort(st._ctx, enabled)
+            st.set_world(sc)
+            st.set_camera(cam)
+            st.render(2)
+            outs.append(st.read_framebuffer())
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_reset_restarts_accumulation(mrt):
+    sc = mrt.scene_default()
+    with mrt.State(mrt.Args(32, 20, 2, 8), seed=6) as st:
+        st.set_world(sc)
+        st.render(3)
+        a3 = st.read_framebuffer()
+        st.reset()
+        assert st.frames_done == 0 and st.locals.framebuffer_weight == 0.0
+        st.render(3)
+        assert np.array_equal(st.read_framebuffer(), a3)
+
+
+def test_many_spheres_blocks_and_padding(mrt, oracle):
+    """More than one 512-sphere block, a count that is not a multiple of 16, and dielectrics."""
+    sc, cam = mrt.scene_stress(3, 33)          # 1090 spheres
+    ref = oracle_render(oracle, sc, cam, 64, 36, 2, 12, 8)
+    got, _, _ = gpu_render(mrt, sc, cam, 64, 36, 2, 12, 8)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+
+
+def test_pathological_overlapping_spheres(mrt, oracle):
+    """Every ray is a candidate for every sphere (concentric shells): stresses the candidate walk and ties."""
+    n = 70
+    sc = np.zeros(n, mrt.SPHERE_DTYPE)
+    for i in range(n):
+        sc[i] = ((0, 0, -3), 0.5 + 0.01 * (i % 35), 1 + (i % 3), (0.8, 0.7, 0.6), 0.2 if i % 3 == 1 else 1.5)
+    ref = oracle_render(oracle, sc, None, 48, 27, 3, 10, 9)
+    got, _, _ = gpu_render(mrt, sc, None, 48, 27, 3, 10, 9)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+
+
+def test_empty_world_is_all_sky(mrt, oracle):
+    sc = np.zeros(0, mrt.SPHERE_DTYPE)
+    got, c, _ = gpu_render(mrt, sc, None, 32, 18, 2, 8, 1)
+    ref = oracle_render(oracle, sc, None, 32, 18, 2, 8, 1)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert c["world_hit_calls"] == 32 * 18 * 2

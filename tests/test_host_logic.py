@@ -1,0 +1,111 @@
+"""Host-side logic of the product (no GPU): Args size rule, scene packing, camera derivation,
+seeding and the accumulation schedule -- each against the reference's stated behaviour and
+against the oracle's independent restatement."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import to_oracle_camera, to_oracle_spheres
+
+
+def test_args_defaults_and_size_rule(mrt):
+    a = mrt.Args()                                    # lib.rs:27-37
+    assert (a.width, a.height, a.samples_per_frame, a.ray_depth, a.max_framebuffer_weight) == (0, 0, 1, 50, 1.0)
+    assert (a.resolved().width, a.resolved().height) == (800, 600)       # both 0 -> default size
+    r = mrt.Args(width=300).resolved()                 # lib.rs:113-134: one zero -> square
+    assert (r.width, r.height) == (300, 300)
+    r = mrt.Args(height=200).resolved()
+    assert (r.width, r.height) == (200, 200)
+    r = mrt.Args(400, 225).resolved()
+    assert (r.width, r.height) == (400, 225)
+
+
+def test_default_scene_is_the_references(mrt):
+    s = mrt.scene_default()                            # lib.rs:687-720
+    assert len(s) == 4
+    assert list(s["material_ty"]) == [1, 1, 2, 2]
+    assert np.allclose(s["center"], [[0, -100.5, -1], [0, 0, -1], [-1, 0, -1], [1, 0, -1]])
+    assert np.allclose(s["radius"], [100, 0.5, 0.5, 0.5])
+    assert np.allclose(s["albedo"][3], [0.8, 0.6, 0.2]) and np.isclose(s["param"][2], 0.3) and s["param"][3] == 1.0
+
+
+def test_pack_matches_reference_indices_and_oracle(mrt, oracle):
+    w, vec4, f32, i32 = mrt.pack_world(mrt.scene_default())             # lib.rs:722-799
+    assert vec4.shape == (8, 4) and len(f32) == 6 and len(i32) == 8
+    assert (w.spheres.center_base_idx, w.spheres.radius_base_idx, w.spheres.material_ty_base_idx,
+            w.spheres.material_idx_base_idx, w.spheres.length) == (0, 0, 0, 4, 4)
+    assert (w.lambertians.albedo_base_idx, w.lambertians.length) == (4, 2)
+    assert (w.metals.albedo_base_idx, w.metals.fuzz_base_idx, w.metals.length) == (6, 4, 2)
+    assert list(i32) == [1, 1, 2, 2, 0, 1, 0, 1]
+    for scene in (mrt.scene_default(), mrt.scene_cover(1, True)[0], mrt.scene_cover(3, False)[0],
+                  mrt.scene_stress(2, 12)[0]):
+        w, vec4, f32, i32 = mrt.pack_world(scene)
+        pw = oracle.pack_world(to_oracle_spheres(oracle, scene))
+        assert bytes(w) == bytes(pw.world)
+        assert np.array_equal(vec4, pw.vec4) and np.array_equal(f32, pw.f32) and np.array_equal(i32, pw.i32)
+
+
+def test_pack_rejects_unknown_material(mrt):
+    s = mrt.scene_default()
+    s["material_ty"][1] = 7
+    with pytest.raises(mrt.MrtError):
+        mrt.pack_world(s)
+
+
+def test_cover_scene_shape(mrt):
+    glass, cam = mrt.scene_cover(1, True)
+    metal, cam2 = mrt.scene_cover(1, False)
+    assert 470 <= len(glass) <= 490 and len(glass) == len(metal)
+    assert np.array_equal(glass["center"], metal["center"])            # same geometry, C2 vs C3 materials
+    assert (glass["material_ty"] == 3).sum() > 5 and (metal["material_ty"] == 3).sum() == 0
+    assert cam.defocus_angle_deg > 0 and cam2.defocus_angle_deg == 0
+    assert tuple(cam.lookfrom) == (13.0, 2.0, 3.0) and cam.vfov_deg == 20.0
+    big = glass[-3:]
+    assert np.allclose(big["radius"], 1.0) and np.allclose(big["center"][:, 0], [0, -4, 4])
+    st, _ = mrt.scene_stress(1, 100)
+    assert len(st) == 10001
+
+
+def test_camera_derive_matches_oracle(mrt, oracle):
+    cams = [mrt.Camera(), mrt.scene_cover(1, True)[1], mrt.scene_cover(1, False)[1], mrt.scene_stress(1, 30)[1],
+            mrt.Camera(1, (1, 2, 3), (-4, 0.5, 9), (0.1, 1, 0), 47.0, 1.3, 7.5)]
+    for cam in cams:
+        got = mrt.camera_derive(cam)
+        ref = oracle.camera_derive(to_oracle_camera(oracle, cam))
+        assert bytes(got) == bytes(ref)
+    with pytest.raises(mrt.MrtError):
+        mrt.camera_derive(mrt.Camera(1, (0, 0, 0), (0, 0, 0)))          # lookfrom == lookat
+
+
+def test_schedule_and_seeds_match_oracle(mrt, oracle):
+    for n in range(0, 40):
+        for mw in (1.0, 0.5, 0.9):
+            assert mrt.frame_weight(n, mw) == oracle.frame_weight(n, mw)
+    assert mrt.frame_weight(0, 1.0) == 0.0 and mrt.frame_weight(1, 1.0) == 0.5      # lib.rs:301-304, 424
+    for seed in (0, 1, 2 ** 63 + 5):
+        for f in (0, 1, 2, 1000):
+            assert mrt.frame_shuffle(seed, f) == oracle.frame_shuffle(seed, f)
+        assert mrt.frame_shuffle(seed, 0) == [0, 0, 0, 0]                              # lib.rs:422
+        one = (C.c_uint32 * 4)()
+        for p in (0, 1, 12345, 1920 * 1080 - 1, 2 ** 33):
+            oracle.lib().orc_pixel_seed(seed, p, one)
+            assert mrt.pixel_seed(seed, p) == list(one)
+
+
+def test_image_writers(mrt, tmp_path):
+    img = np.zeros((3, 4, 4), np.float32)
+    img[0, :, 0] = 1.0           # bottom row red
+    img[2, :, 2] = 0.25          # top row blue 0.25
+    p = str(tmp_path / "a.pfm")
+    mrt.write_image(p, img)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"PF\n4 3\n-1.0\n")
+    body = np.frombuffer(raw[len(b"PF\n4 3\n-1.0\n"):], np.float32).reshape(3, 4, 3)
+    assert np.array_equal(body, img[..., :3])           # PFM is bottom-up like the framebuffer
+    p = str(tmp_path / "a.ppm")
+    mrt.write_image(p, img)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"P6\n4 3\n255\n")
+    body = np.frombuffer(raw[len(b"P6\n4 3\n255\n"):], np.uint8).reshape(3, 4, 3)
+    assert body[2, 0, 0] == 255 and body[0, 0, 2] == 128 and body[1].sum() == 0     # flipped, gamma 2
