@@ -15,8 +15,9 @@ HDRS     := $(CSRC)/mrt_internal.h include/myraytracer_amd.h
 
 all: $(LIB) $(CLI) oracle
 
-$(LIB): $(SRCS) $(HDRS)
+$(LIB): $(SRCS) $(HDRS) scripts/check_isa.py
 	@mkdir -p $(LIBDIR)
+	python3 scripts/check_isa.py
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
 
 $(CLI): $(CSRC)/native_runner.cpp $(LIB)

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Build-time check of the hand-issued scalar loads in mrt::render_kernel.
+
+The discriminant sweep issues `s_load_dwordx16` in inline asm and waits for them one group
+later.  hipcc does not know the destinations are in flight between those two statements, so
+a spill (v_writelane), copy (s_mov) or reuse of those SGPRs in between would read or clobber
+data that has not landed.  This script compiles kernels.hip to ISA, rebuilds the control-flow
+graph of every render_kernel instantiation and verifies that on every path from a hand-issued
+load to the first `s_waitcnt ... lgkmcnt(0)` (ours or hipcc's: either lands all outstanding
+scalar loads) no instruction reads or writes the load's destination SGPRs.  Exit code 0 = verified.
+
+    python scripts/check_isa.py [--flags "<hipcc flags>"]
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "myraytracer_amd", "csrc", "kernels.hip")
+DEFAULT_FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-vectorize -fno-slp-vectorize"
+
+
+def sregs(text):
+    """All SGPR indices mentioned in an operand string."""
+    out = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bs(\d+)\b", text):
+        out.add(int(a))
+    return out
+
+
+def check_kernel(name, lines):
+    """Forward reachability from every hand-issued s_load_dwordx16 to the first lgkmcnt(0) wait on each
+    path (any such wait -- ours or hipcc's -- lands every outstanding scalar load): nothing on the way may
+    read or write the load's destination SGPRs."""
+    n = len(lines)
+    label_at = {}
+    for k, l in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            label_at[m.group(1)] = k
+
+    def instr(k):
+        return lines[k].split(";")[0].strip()
+
+    def successors(k):
+        l = instr(k)
+        parts = l.split()
+        if parts and parts[0] == "s_branch":
+            return [label_at[parts[1]]]
+        if parts and parts[0].startswith("s_cbranch"):
+            return [label_at[parts[1]], k + 1]
+        if parts and parts[0] == "s_endpgm":
+            return []
+        return [k + 1] if k + 1 < n else []
+
+    errors, loads = [], 0
+    for k0 in range(n):
+        m = re.search(r"^\s*s_load_dwordx16\s+(s\[\d+:\d+\])", lines[k0])
+        if not m:
+            continue
+        # only hand-issued loads (inside an asm statement); hipcc's own are tracked by its waitcnt pass
+        j = k0
+        while j >= 0 and "#ASMSTART" not in lines[j] and "#ASMEND" not in lines[j]:
+            j -= 1
+        if j < 0 or "#ASMSTART" not in lines[j]:
+            continue
+        loads += 1
+        dest = sregs(m.group(1))
+        seen, stack = set(), list(successors(k0))
+        while stack:
+            k = stack.pop()
+            if k in seen or k >= n:
+                continue
+            seen.add(k)
+            l = instr(k)
+            if l.startswith("s_waitcnt") and "lgkmcnt(0)" in l:
+                continue                                   # everything has landed on this path
+            if l and not l.endswith(":") and not l.startswith((".", "s_load_dwordx16")):
+                ops = l.split(None, 1)[1] if " " in l or "\t" in l else ""
+                if sregs(ops) & dest:
+                    errors.append(f"{name}: `{l}` (line {k}) touches {m.group(1)} while its load from line {k0} "
+                                  f"may still be in flight")
+            elif l.startswith("s_load_dwordx16"):
+                ops = l.split(None, 1)[1]
+                if sregs(ops.split(",", 1)[1]) & dest:
+                    errors.append(f"{name}: `{l}` (line {k}) reads {m.group(1)} while in flight")
+            stack.extend(successors(k))
+    if loads == 0:
+        errors.append(f"{name}: no hand-issued s_load_dwordx16 found (sweep not recognised)")
+    return errors
+
+
+def main():
+    flags = DEFAULT_FLAGS
+    if "--flags" in sys.argv:
+        flags = sys.argv[sys.argv.index("--flags") + 1]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", *flags.split(), "--cuda-device-only", "-S", "-o", out, SRC],
+                              stderr=subprocess.DEVNULL)
+        text = open(out).read().splitlines()
+    errors, checked = [], 0
+    i = 0
+    while i < len(text):
+        m = re.match(r"^(_ZN3mrt\S*render_kernel\S*):", text[i])
+        if m:
+            j = i
+            while "s_endpgm" not in text[j]:
+                j += 1
+            errors += check_kernel(m.group(1), text[i:j + 1])
+            checked += 1
+            i = j
+        i += 1
+    if checked == 0:
+        errors.append("no render_kernel instantiation found in the ISA")
+    for e in errors:
+        print("check_isa:", e)
+    print(f"check_isa: {checked} render_kernel instantiation(s) checked, {len(errors)} problem(s)")
+    return 1 if errors else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

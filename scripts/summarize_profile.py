@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (scripts/profile.sh) into committed summaries under profiles/:
+   profiles/<round>_<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary
+   profiles/<round>_<tag>_pmc.json           per-launch means of the PMC passes + derived numbers
+   profiles/hbm_traffic.json                 HBM bytes per launch keyed by workload (bench.py reads it)
+usage: scripts/summarize_profile.py <tag> <round> [workload_key]"""
+import collections, csv, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, rnd = sys.argv[1], sys.argv[2]
+key = sys.argv[3] if len(sys.argv) > 3 else None
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv"))
+vals, launches = {}, {}
+for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
+    f = os.path.join(src, p, f"{p}_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "render_kernel<" in r["Kernel_Name"] and "true>(" not in r["Kernel_Name"].split("render_kernel")[1][:14].replace("<true, false>", ""):
+            pass
+        if "render_kernel" in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]:      # skip the PILOT instantiation
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        vals[k] = sum(v) / len(v)
+        launches[k] = len(v)
+out = {"source": f"gpurun_out/prof_{tag} (scripts/profile.sh: separate rocprofv3 --pmc passes)", "per_launch_mean": vals,
+       "launches_averaged": launches}
+if "GRBM_GUI_ACTIVE" in vals:
+    cyc = vals["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
+    out["derived"] = {"kernel_cycles": cyc}
+    if "SQ_INSTS_VALU" in vals:
+        out["derived"]["valu_issue_utilisation_at_2cyc_per_inst"] = vals["SQ_INSTS_VALU"] * 2.0 / (1024 * cyc)
+    if "SQ_THREAD_CYCLES_VALU" in vals and "SQ_ACTIVE_INST_VALU" in vals:
+        out["derived"]["valu_thread_utilisation"] = vals["SQ_THREAD_CYCLES_VALU"] / (vals["SQ_ACTIVE_INST_VALU"] * 64.0)
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    # MI355X_MICROARCH.md §HBM: counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of
+    # a wide coalesced (16 B/lane) read stream -> doubled; WRITE_SIZE is exact for 16 B/lane stores.
+    hbm = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    out["derived"]["hbm_bytes_per_launch"] = hbm
+    out["derived"]["hbm_note"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction per MI355X_MICROARCH.md"
+    if key:
+        tj_path = os.path.join(dst, "hbm_traffic.json")
+        tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+        tj[key] = hbm
+        tj["_note"] = "HBM bytes per render_kernel launch from rocprofv3 PMC passes; see profiles/*_pmc.json"
+        json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(dst, f"{rnd}_{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+for log in ("bench_trace.log",):
+    lines = [l for l in open(os.path.join(src, log)) if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, f"{rnd}_{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+print(json.dumps(out.get("derived", {}), indent=1))
+print(open(os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv")).read())

@@ -63,3 +63,12 @@ def test_product_never_imports_the_oracle():
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "rt_oracle" not in text and "pyoracle" not in text, os.path.join(dirpath, f)
                     assert not re.search(r"#include\s+[\"<].*oracle", text), os.path.join(dirpath, f)
+
+
+def test_hand_issued_scalar_loads_are_safe_in_the_built_isa():
+    """scripts/check_isa.py: no compiler-generated instruction touches an SGPR while the sweep's
+    inline-asm s_load into it may still be in flight."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
