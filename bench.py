@@ -106,7 +106,8 @@ def main():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MRT_BENCH_FORCE_DIST") == "1"   # the env var rehearses the RCCL path on one GPU
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     width, height, spp = WORKLOADS.get(a.gpus, WORKLOADS[1])
@@ -129,17 +130,17 @@ def main():
     if cam is not None:
         st.set_camera(cam)
     _, _, lrows, _ = st.shard_info()
-    staging = torch.empty((world, lrows, width, 4), dtype=torch.float32, device=device) if (world > 1 and rank == 0) else None
+    staging = torch.empty((world, lrows, width, 4), dtype=torch.float32, device=device) if (use_dist and rank == 0) else None
 
     def step():
         st.redraw()                                    # async on torch's current stream
-        if world > 1:
+        if use_dist:
             return mdist.gather_framebuffer(mdist.framebuffer_tensor(st, device), height, 0, staging)
         return None
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -160,7 +161,7 @@ def main():
     stats = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=device)
     sums = torch.tensor([c1["world_hit_calls"] - c0["world_hit_calls"], c1["samples"] - c0["samples"],
                          c1["lane_slots"] - c0["lane_slots"]], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     elapsed_max, kernel_ms_max = float(stats[0]), float(stats[1])
@@ -210,7 +211,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     st.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

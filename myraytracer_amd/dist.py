@@ -47,9 +47,9 @@ def gather_framebuffer(local: torch.Tensor, height: int, dst: int = 0,
     local: [local_rows, W, 4] f32 on this rank's device.  `out` (dst only) may be a
     preallocated [world, local_rows, W, 4] staging tensor.  Returns the image on dst, None elsewhere.
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return unshard(local.unsqueeze(0), height)
+    world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if rank == dst:
         if out is None:
