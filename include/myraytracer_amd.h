@@ -209,10 +209,15 @@ int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since c
 /* Diagnostic: the 16 raw u64 counter slots (0..3 = mrt_counters; 4.. are phase cycle sums
  * written only by the -DMRT_STAMPS profiling build). */
 int mrt_debug_read_counters(mrt_ctx* ctx, uint64_t out[16]);
-/* Diagnostic A/B switch: 0 launches tiles in row-major order instead of heaviest-first. */
+/* Diagnostic: per-pixel cost (bounce-loop trips) of the last frame, local_rows*width u32. */
+int mrt_debug_read_pixel_costs(mrt_ctx* ctx, uint32_t* out, size_t cap);
+/* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */
 int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);
+/* Diagnostic / tuning: pilot samples per pixel, waves per CU (0 = automatic).  Before the first
+ * redraw only. */
+int mrt_debug_set_schedule(mrt_ctx* ctx, uint32_t pilot_spp, int waves_per_cu);
 /* Diagnostic: per-wave log {t_start, t_end (100 MHz ticks), loop trips, bounces}, 4 u64 per 8x8
- * tile, written only by the -DMRT_STAMPS build.  out == NULL allocates the log. */
+ * persistent wave, written only by the -DMRT_STAMPS build.  out == NULL allocates the log. */
 int mrt_debug_wave_log(mrt_ctx* ctx, uint64_t* out, size_t cap_waves, size_t* n_waves);
 /* Elapsed GPU time (ms) of the most recent redraw's render kernel, from HIP events on
  * the launch stream.  Synchronises on the stop event. */

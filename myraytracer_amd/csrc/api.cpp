@@ -53,12 +53,15 @@ struct mrt_ctx {
     float* d_fb[2] = {nullptr, nullptr};   // [target, secondary] ping-pong (lib.rs:505-543)
     int target = 0;                        // index of the buffer the NEXT redraw writes
     unsigned long long* d_counters = nullptr;
-    // launch order (tile_order.hip): costs written by frame n order the launch of frame n+1
+    // tile queue (tile_order.hip): tile costs measured in frame n order the queue of frame n+1
     uint32_t* d_tile_cost = nullptr;
     uint32_t* d_tile_order = nullptr;
-    uint32_t* d_sort_scratch = nullptr;
-    uint32_t tiles_x = 0, n_tiles = 0;
-    bool cost_valid = false;
+    uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter
+    void* d_pix_acc = nullptr;             // per-pixel colour sums + costs, render -> finalize
+    uint32_t tiles_x = 0, n_tiles = 0, n_waves = 0;
+    uint32_t pilot_spp = 2;
+    int waves_per_cu_override = 0;
+    bool cost_valid = false;               // d_tile_cost holds a usable estimate for the current scene
     bool lpt_enabled = true;
     unsigned long long* d_wave_log = nullptr;   // diagnostic, see mrt_debug_wave_log
     size_t wave_log_waves = 0;
@@ -105,8 +108,10 @@ void free_frame_buffers(mrt_ctx* c) {
     if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
     if (c->d_tile_order) (void)hipFree(c->d_tile_order);
     if (c->d_sort_scratch) (void)hipFree(c->d_sort_scratch);
+    if (c->d_pix_acc) (void)hipFree(c->d_pix_acc);
     c->d_seeds = nullptr; c->d_fb[0] = c->d_fb[1] = nullptr;
     c->d_tile_cost = c->d_tile_order = c->d_sort_scratch = nullptr;
+    c->d_pix_acc = nullptr;
     c->cost_valid = false;
 }
 
@@ -134,7 +139,18 @@ int alloc_frame_buffers(mrt_ctx* c) {
     c->n_tiles = c->tiles_x * c->local_bands;
     HIP_TRY(c, hipMalloc(&c->d_tile_cost, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&c->d_tile_order, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&c->d_sort_scratch, 1024 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_sort_scratch, (1024 + 16) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_pix_acc, (n ? n : 1) * 16));
+    HIP_TRY(c, hipMemsetAsync(c->d_pix_acc, 0, (n ? n : 1) * 16, c->stream));
+    // as many persistent single-wave workgroups as the chip holds
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+        int wpc = 0;
+        if (mrt::render_waves_per_cu(&wpc) != 0 || wpc <= 0) wpc = 16;
+        if (c->waves_per_cu_override > 0) wpc = c->waves_per_cu_override;
+        c->n_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)wpc;
+    }
     int e = mrt::launch_fill_seeds(c->d_seeds, c->seed, c->args.width, c->args.height, c->shard_rank,
                                    c->shard_world, c->local_bands, c->stream);
     if (e) return fail(c, MRT_ERR_HIP, "fill_seeds launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -526,14 +542,17 @@ int mrt_redraw(mrt_ctx* c) {
     p.counters = c->d_counters;
     p.wave_log = c->d_wave_log;
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
-    p.tile_cost = c->d_tile_cost;
+    p.tile_queue = c->d_sort_scratch + 1024;
     p.tile_order = nullptr;
-    // Launch order: heaviest tile first, from the previous frame's per-tile cost; before the
-    // first frame of a scene a 1-spp pilot pass (no output) provides the estimate when the
-    // frame is long enough to pay for it.
+    p.pilot_spp = c->pilot_spp;
+    p.tile_cost = c->d_tile_cost;
+    p.pix_acc = c->d_pix_acc;
+    // The tile queue is ordered by the previous frame's per-tile cost, heaviest first; before
+    // the first frame of a scene a small pilot launch (no output) provides the estimate when
+    // the frame is long enough to pay for it.  Without an estimate: index order.
     if (c->lpt_enabled) {
-        if (!c->cost_valid && c->locals.samples_per_frame >= 16u) {
-            int pe = mrt::launch_render(p, true, c->stream);
+        if (!c->cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
+            int pe = mrt::launch_render(p, true, c->n_waves, c->stream);
             if (pe) return fail(c, MRT_ERR_HIP, "pilot launch failed: %s", hipGetErrorString((hipError_t)pe));
             c->cost_valid = true;
         }
@@ -545,7 +564,7 @@ int mrt_redraw(mrt_ctx* c) {
     }
     const uint32_t slot = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
     HIP_TRY(c, hipEventRecord(c->ev_start[slot], c->stream));
-    int e = mrt::launch_render(p, false, c->stream);
+    int e = mrt::launch_render(p, false, c->n_waves, c->stream);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
     HIP_TRY(c, hipEventRecord(c->ev_stop[slot], c->stream));
     c->timed_frames++;
@@ -567,11 +586,37 @@ int mrt_render(mrt_ctx* c, uint32_t frames) {
     return MRT_OK;
 }
 
-// diagnostic / A-B switch: 0 = launch tiles in row-major order
+// diagnostic: per-pixel cost (bounce-loop trips) of the last frame, this shard's packed rows
+int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
+    if (!c || !out) return MRT_ERR_INVALID_ARG;
+    const size_t n = local_texels(c);
+    if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_read_pixel_costs: need %zu", n);
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<uint32_t> tmp(n * 4);
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) out[i] = tmp[4 * i + 3];
+    return MRT_OK;
+}
+
+// diagnostic / A-B switch: 0 = tile queue in index order instead of heaviest-first
 int mrt_debug_set_tile_sort(mrt_ctx* c, int enabled) {
     if (!c) return MRT_ERR_INVALID_ARG;
     c->lpt_enabled = enabled != 0;
     return MRT_OK;
+}
+
+// diagnostic / tuning: pilot spp, waves per CU (0 = automatic).
+// Call before rendering.
+int mrt_debug_set_schedule(mrt_ctx* c, uint32_t pilot_spp, int waves_per_cu) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pilot_spp = pilot_spp ? pilot_spp : 1;
+    c->waves_per_cu_override = waves_per_cu;
+    const uint32_t frames = c->frames_done;
+    if (frames != 0) return fail(c, MRT_ERR_STATE, "mrt_debug_set_schedule: frames already rendered");
+    return alloc_frame_buffers(c);
 }
 
 int mrt_sync(mrt_ctx* c) {
@@ -661,7 +706,7 @@ int mrt_debug_read_counters(mrt_ctx* c, uint64_t out[16]) {
 int mrt_debug_wave_log(mrt_ctx* c, uint64_t* out, size_t cap_waves, size_t* n_waves) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t n = c->n_tiles;
+    const size_t n = c->n_waves;
     if (n_waves) *n_waves = n;
     if (!c->d_wave_log || c->wave_log_waves != n) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -154,7 +154,7 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 d, float a, uint32
 
 // Candidate masks: per wave kBlockChunks x 64 lanes of u16 (one 16-sphere sign mask per chunk
 // and lane), chunk-major so that the 64 lanes of one access touch 128 consecutive bytes.
-// Diagnostic build only (-DMRT_STAMPS, scripts/phase_profile.sh): s_memtime shares of the
+// Diagnostic build only (-DMRT_STAMPS, scripts/phase_profile.py): s_memtime shares of the
 // phases of the bounce loop, summed per wave into counters[4..].  Never in the product .so.
 #ifdef MRT_STAMPS
 #define MRT_STAMP(k)                                                        \
@@ -171,52 +171,63 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 d, float a, uint32
 
 constexpr uint32_t kBlockChunks = 32;     // 32 chunks x 16 spheres = 512 spheres between exact passes
 
+// lanes below `lane` whose bit is set in the 64-bit ballot `mask`
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// What render_kernel leaves per pixel for finalize_kernel: the colour sum of the frame's samples
+// and the pixel's cost (trips of the bounce loop).
+struct alignas(16) PixAcc { float r, g, b; uint32_t cost; };
+
+// Persistent waves and a global heaviest-first tile queue:
+//  * the grid is as many single-wave workgroups as the chip holds; every wave starts at t = 0
+//    and pulls 8x8 tiles from ONE global queue (an atomic counter over the tile list sorted by
+//    estimated cost, heaviest first -- tile_order.hip) whenever one of its lanes would run dry;
+//  * a lane owns one pixel for all of the frame's samples, as in the fragment shader -- the
+//    reference's one sequential Xoshiro128+ stream per pixel (shader.wgsl:377-382) -- and when
+//    the pixel is finished it takes the next pixel from the wave's small FIFO instead of idling
+//    until the slowest pixel of its tile is done;
+//  * finished colour sums are left in HBM; finalize_kernel turns them into the framebuffer with
+//    coalesced whole-line stores.
+constexpr uint32_t kRingCap = 128;        // < 64 waiting + 64 from a new tile; power of two
+
 template <bool COUNT, bool PILOT>
-// One wave per workgroup: a finished wave frees its slot at once (with 4-wave workgroups
-// the LDS and the launch slot were held until the slowest of the four waves ended).
 __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     __shared__ uint16_t mask_lds[kBlockChunks * 64];
-
+    __shared__ uint32_t ring[kRingCap];       // FIFO of waiting pixels: tile << 6 | lane-in-tile
     const uint32_t lane = threadIdx.x;
-    uint16_t* const masks = mask_lds + lane;   // chunk c at masks[c*64]
+    uint16_t* const masks = mask_lds + lane;                  // chunk c at masks[c*64]
 
     const uint32_t W = P.locals.shape[0], H = P.locals.shape[1];
-    // Launch order is heaviest tile first (longest-processing-time scheduling, tile_order.hip):
-    // with only ~4.5 waves per wave slot at 1920x1080 the heaviest tiles would otherwise start
-    // late and run on an emptying chip for the last fifth of the kernel.
-    const uint32_t tile = P.tile_order ? P.tile_order[blockIdx.x] : blockIdx.x;
-    const uint32_t tile_x = tile % P.tiles_x, band = tile / P.tiles_x;
-    const uint32_t px = tile_x * kTileW + (lane & 7u);
-    const uint32_t lrow = band * kBandRows + (lane >> 3);                             // row in this shard
-    const uint32_t py = (band * P.shard_world + P.shard_rank) * kBandRows + (lane >> 3);  // global row, 0 = bottom
-    const bool valid = (px < W) && (py < H);
-    const size_t texel = (size_t)lrow * W + px;
-
-    const uint32_t spp = PILOT ? 1u : P.locals.samples_per_frame;   // pilot: 1 spp, cost estimate only
+    const uint32_t spp = PILOT ? P.pilot_spp : P.locals.samples_per_frame;
     const uint32_t n_padded = P.n_padded;
     const SphereRec* __restrict__ spheres = P.spheres;
     const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.spheres;
+    PixAcc* __restrict__ st_acc = reinterpret_cast<PixAcc*>(P.pix_acc);
+    const float pixel_side = 2.0f / (float)H;                 // fs_main :373
 
-    // fs_main prologue, shader.wgsl:373-377
-    const float pixel_side = 2.0f / (float)H;
-    const float base_x = (((float)px + 0.5f) - 0.5f * (float)W) * pixel_side;
-    const float base_y = (((float)py + 0.5f) - 0.5f * (float)H) * pixel_side;
+    // pixel id q = (tile << 6) | lane-in-tile -> coordinates
+    auto locate = [&](uint32_t q, uint32_t& px, uint32_t& py, uint32_t& texel) -> bool {
+        const uint32_t tile = q >> 6, l = q & 63u;
+        const uint32_t tile_x = tile % P.tiles_x, band = tile / P.tiles_x;
+        px = tile_x * kTileW + (l & 7u);
+        py = (band * P.shard_world + P.shard_rank) * kBandRows + (l >> 3);    // global row, 0 = bottom
+        texel = (band * kBandRows + (l >> 3)) * W + px;                       // row in this shard (< 2^32 texels)
+        return px < W && py < H;
+    };
 
-    Rng rng; rng.draws = 0;
-    rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    if (valid) {                                                   // xoshiro128plus_load, :44-47
-        const uint4 s = reinterpret_cast<const uint4*>(P.seeds)[texel];
-        rng.s0 = s.x ^ P.locals.rng_shuffle[0];
-        rng.s1 = s.y ^ P.locals.rng_shuffle[1];
-        rng.s2 = s.z ^ P.locals.rng_shuffle[2];
-        rng.s3 = s.w ^ P.locals.rng_shuffle[3];
-    }
+    uint32_t head = 0, tail = 0, avail = 0;     // wave-uniform FIFO cursors (mod kRingCap) and fill
+    bool queue_empty = false;                   // wave-uniform: the global tile queue is exhausted
 
+    // ---- per-lane task state
+    bool has_task = false, task_done = false, need_sample = false;
+    uint32_t s_done = 0, pix_trips = 0, texel = 0;
+    float base_x = 0.0f, base_y = 0.0f;
+    Rng rng; rng.draws = 0; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     V3 color = v3(0.0f, 0.0f, 0.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, -1.0f), att = v3(1.0f, 1.0f, 1.0f);
     uint32_t depth_left = 0, started = 0, bounces = 0, trips = 0;
-    bool active = valid && spp > 0u;
-    bool need_sample = true;
 
 #ifdef MRT_STAMPS
     uint64_t phase_[6] = {0, 0, 0, 0, 0, 0};
@@ -224,206 +235,244 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     const uint64_t wave_t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    while (active) {
+    for (;;) {
+        // ---- release: the pixel's last sample is done -> leave its colour sum for finalize_kernel
+        const bool release = has_task && task_done;
+        if (release) {
+            PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
+            st_acc[texel] = sa;
+            has_task = false;
+        }
+        // ---- refill: lanes would run dry -> take the next (heaviest remaining) tile of the frame
+        const unsigned long long need = __ballot(!has_task);
+        if (!queue_empty && avail < (uint32_t)__popcll(need)) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(P.tile_queue, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= P.n_tiles) {
+                queue_empty = true;
+            } else {
+                const uint32_t tile = P.tile_order ? P.tile_order[t] : t;
+                uint32_t fx, fy, ft;
+                const uint32_t fq = (tile << 6) | lane;
+                const bool ok = locate(fq, fx, fy, ft);
+                const unsigned long long m = __ballot(ok);
+                if (ok) ring[(tail + rank_in(m)) & (kRingCap - 1u)] = fq;
+                const uint32_t nf = (uint32_t)__popcll(m);
+                tail += nf;
+                avail += nf;
+            }
+        }
+        // ---- acquire: idle lanes take the pixels at the front of the FIFO
+        if (need != 0ull && avail != 0u) {
+            const uint32_t rk = rank_in(need);
+            const bool take = !has_task && rk < avail;
+            if (take) {
+                uint32_t px, py;
+                locate(ring[(head + rk) & (kRingCap - 1u)], px, py, texel);
+                base_x = (((float)px + 0.5f) - 0.5f * (float)W) * pixel_side;      // fs_main :374
+                base_y = (((float)py + 0.5f) - 0.5f * (float)H) * pixel_side;
+                const uint4 sd = reinterpret_cast<const uint4*>(P.seeds)[texel];      // xoshiro128plus_load :44-47
+                rng.s0 = sd.x ^ P.locals.rng_shuffle[0];
+                rng.s1 = sd.y ^ P.locals.rng_shuffle[1];
+                rng.s2 = sd.z ^ P.locals.rng_shuffle[2];
+                rng.s3 = sd.w ^ P.locals.rng_shuffle[3];
+                color = v3(0.0f, 0.0f, 0.0f);                                         // :376
+                s_done = 0;
+                pix_trips = 0;
+                has_task = true;
+                task_done = (spp == 0u);                // nothing to draw: colour 0/0, as the reference
+                need_sample = !task_done;
+            }
+            const uint32_t np = (uint32_t)__popcll(need);
+            const uint32_t took = np < avail ? np : avail;
+            head += took;
+            avail -= took;
+        }
+        if (!__any(has_task)) {
+            if (queue_empty) break;
+            continue;                       // an all-invalid edge tile: pull the next one
+        }
         trips++;
         MRT_STAMP(5);
-        if (need_sample) {
-            // one trip of the sample loop head, shader.wgsl:378-381
-            float u = rng_f32(rng); float v = rng_f32(rng);            // :71-75, x then y
-            float vx = base_x + u * pixel_side;
-            float vy = base_y + v * pixel_side;
-            if (P.cam.mode == 0) {
-                o = v3(0.0f, 0.0f, 0.0f);                               // ORIGIN, :361
-                d = normalize3(v3(vx, vy, -1.0f));                      // :381
-            } else {
-                // extension: look-at thin-lens camera over the same (vx, vy)
-                V3 p = v3((vx * P.cam.su[0] + vy * P.cam.sv[0]) - P.cam.fw[0],
-                          (vx * P.cam.su[1] + vy * P.cam.sv[1]) - P.cam.fw[1],
-                          (vx * P.cam.su[2] + vy * P.cam.sv[2]) - P.cam.fw[2]);
-                o = v3(P.cam.origin[0], P.cam.origin[1], P.cam.origin[2]);
-                if (P.cam.defocus) {
-                    float lx, ly;
-                    do {                                                // unit disk by rejection
-                        float qx = rng_f32(rng); float qy = rng_f32(rng);
-                        lx = 2.0f * qx - 1.0f; ly = 2.0f * qy - 1.0f;
-                    } while (__builtin_fmaf(ly, ly, lx * lx) > 1.0f);
-                    V3 off = v3(lx * P.cam.ru[0] + ly * P.cam.rv[0],
-                                lx * P.cam.ru[1] + ly * P.cam.rv[1],
-                                lx * P.cam.ru[2] + ly * P.cam.rv[2]);
-                    o = o + off;
-                    d = normalize3(p - off);
+
+        if (has_task && !task_done) {
+            pix_trips++;
+            if (need_sample) {
+                // one trip of the sample loop head, shader.wgsl:378-381
+                float u = rng_f32(rng); float v = rng_f32(rng);            // :71-75, x then y
+                float vx = base_x + u * pixel_side;
+                float vy = base_y + v * pixel_side;
+                if (P.cam.mode == 0) {
+                    o = v3(0.0f, 0.0f, 0.0f);                               // ORIGIN, :361
+                    d = normalize3(v3(vx, vy, -1.0f));                      // :381
                 } else {
-                    d = normalize3(p);
-                }
-            }
-            att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
-            depth_left = P.locals.ray_depth;
-            started++;
-            need_sample = false;
-        }
-        MRT_STAMP(0);
-
-        bool path_done = false;
-        V3 contrib = v3(0.0f, 0.0f, 0.0f);
-
-        if (depth_left == 0u) {
-            path_done = true;                                           // loop :339 not entered -> :357
-        } else {
-            // ------------------------------------------------ world_hit, shader.wgsl:314-329
-            bounces++;
-            const float a = dot3(d, d);                                 // sphere_hit :277 (same for every sphere)
-            float t_sup = 1.0e4f;                                       // :340
-            int32_t best = -1;
-            // A ray with a non-finite component makes every discriminant NaN, which the
-            // reference treats as "not < 0".  Such lanes take the literal loop below.
-            const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
-                                 __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff());
-            // Discriminant sweep + exact pass, in blocks of kBlockChunks x kChunk spheres.
-            // Sphere records are wave-uniform: they are fetched with scalar loads, 8 records (two
-            // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
-            // loads of group g+1, then run the 8 x 12 VALU ops of group g while they fly.
-            Sph8 ga, gb;
-            smem_load8(ga, sph_quads, 0u);
-            for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
-                const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
-                uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
-                uint32_t c = 0;
-                for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
-                    uint32_t bits = 0;
-                    smem_wait_then_load8(ga, gb, sph_quads, i + 8u, bits);  test8(ga, o, d, a, bits);
-                    const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
-                    smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);     test8(gb, o, d, a, bits);
-                    MRT_STAMP(1);
-                    // 16 signs in bits[15:0], sphere i at bit 15; candidate = discriminant >= 0
-                    const uint32_t m = weird ? 0u : (~bits & 0xFFFFu);
-                    masks[c * 64u] = (uint16_t)m;
-                    nz |= (m != 0u ? 1u : 0u) << c;
-                    MRT_STAMP(2);
-                }
-                // exact pass over this block's candidates, each lane in increasing sphere index:
-                // every trip handles one candidate of every lane that still has one
-                uint32_t m = 0, base = 0;
-                while ((nz | m) != 0u) {
-                    if (m == 0u) {
-                        const uint32_t cc = (uint32_t)__builtin_ctz(nz);
-                        nz &= nz - 1u;
-                        m = masks[cc * 64u];
-                        base = blk + cc * kChunk;
-                    }
-                    const uint32_t j = (uint32_t)__builtin_clz(m) - 16u;   // sphere base + j, lowest index first
-                    m &= ~(0x8000u >> j);
-                    const uint32_t idx = base + j;
-                    exact_test(spheres[idx], idx, o, d, a, t_sup, best);
-                }
-            }
-            // the last prefetch is never consumed, but its destination SGPRs must stay reserved
-            // until it has landed
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi));
-            if (weird) {
-                for (uint32_t idx = 0; idx < P.n_spheres; idx++)
-                    exact_test(spheres[idx], idx, o, d, a, t_sup, best);
-            }
-            MRT_STAMP(3);
-
-            if (best < 0) {
-                // color_sky, shader.wgsl:331-334, 343-345
-                float t = 0.5f * d.y + 0.5f;
-                contrib = att * v3(mixf(1.0f, 0.5f, t), mixf(1.0f, 0.7f, t), mixf(1.0f, 1.0f, t));
-                path_done = true;
-            } else {
-                // rest of sphere_hit for the winning sphere, shader.wgsl:298-309
-                const V3 center = load_vec4_xyz(P.vec4_data, P.world.spheres.center_base_idx + best);
-                const float radius = P.f32_data[P.world.spheres.radius_base_idx + best];
-                const int32_t m_ty = P.i32_data[P.world.spheres.material_ty_base_idx + best];
-                const int32_t m_idx = P.i32_data[P.world.spheres.material_idx_base_idx + best];
-                const V3 at = o + t_sup * d;                            // ray_normalized_at :103-105
-                V3 normal = (at - center) / radius;
-                const bool front_face = dot3(normal, d) <= 0.0f;
-                if (!front_face) normal = -normal;
-
-                // dyn_material_scatter, shader.wgsl:244-252
-                V3 albedo = v3(1.0f, 1.0f, 1.0f), ndir = d;
-                bool scattered;
-                if (m_ty == MRT_LAMBERTIAN) {                           // :203-216
-                    albedo = load_vec4_xyz(P.vec4_data, P.world.lambertians.albedo_base_idx + m_idx);
-                    ndir = normal + normalize3(rng_unit_ball(rng));     // unit_sphere :92-94
-                    if (dot3(ndir, ndir) == 0.0f) ndir = normal;
-                    scattered = true;
-                } else if (m_ty == MRT_METAL) {                         // :228-242
-                    const V3 refl = reflect3(d, normal);
-                    const float fuzz = P.f32_data[P.world.metals.fuzz_base_idx + m_idx];
-                    const V3 ball = rng_unit_ball(rng);
-                    ndir = v3(refl.x + fuzz * ball.x, refl.y + fuzz * ball.y, refl.z + fuzz * ball.z);
-                    scattered = !(dot3(ndir, normal) <= 0.0f);
-                    albedo = load_vec4_xyz(P.vec4_data, P.world.metals.albedo_base_idx + m_idx);
-                } else if (m_ty == MRT_DIELECTRIC) {                    // extension, DESIGN.md §3
-                    const float ior = P.f32_data[P.world.dielectrics.ior_base_idx + m_idx];
-                    const float ri = front_face ? (1.0f / ior) : ior;
-                    float cos_t = dot3(-d, normal);
-                    cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;
-                    const float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
-                    const bool cannot_refract = (ri * sin_t) > 1.0f;
-                    float r0 = (1.0f - ri) / (1.0f + ri);
-                    r0 = r0 * r0;
-                    const float x1 = 1.0f - cos_t;
-                    const float x2 = x1 * x1; const float x4 = x2 * x2; const float x5 = x4 * x1;
-                    const float reflectance = r0 + (1.0f - r0) * x5;
-                    const float u = rng_f32(rng);                       // always exactly one draw
-                    if (cannot_refract || reflectance > u) {
-                        ndir = reflect3(d, normal);
+                    // extension: look-at thin-lens camera over the same (vx, vy)
+                    V3 p = v3((vx * P.cam.su[0] + vy * P.cam.sv[0]) - P.cam.fw[0],
+                              (vx * P.cam.su[1] + vy * P.cam.sv[1]) - P.cam.fw[1],
+                              (vx * P.cam.su[2] + vy * P.cam.sv[2]) - P.cam.fw[2]);
+                    o = v3(P.cam.origin[0], P.cam.origin[1], P.cam.origin[2]);
+                    if (P.cam.defocus) {
+                        float lx, ly;
+                        do {                                                // unit disk by rejection
+                            float qx = rng_f32(rng); float qy = rng_f32(rng);
+                            lx = 2.0f * qx - 1.0f; ly = 2.0f * qy - 1.0f;
+                        } while (__builtin_fmaf(ly, ly, lx * lx) > 1.0f);
+                        V3 off = v3(lx * P.cam.ru[0] + ly * P.cam.rv[0],
+                                    lx * P.cam.ru[1] + ly * P.cam.rv[1],
+                                    lx * P.cam.ru[2] + ly * P.cam.rv[2]);
+                        o = o + off;
+                        d = normalize3(p - off);
                     } else {
-                        const V3 perp = v3(ri * (d.x + cos_t * normal.x), ri * (d.y + cos_t * normal.y),
-                                           ri * (d.z + cos_t * normal.z));
-                        const float k = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
-                        ndir = v3(perp.x + k * normal.x, perp.y + k * normal.y, perp.z + k * normal.z);
+                        d = normalize3(p);
                     }
-                    scattered = true;
-                } else {
-                    scattered = false;                                  // :249-251
                 }
+                att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
+                depth_left = P.locals.ray_depth;
+                started++;
+                need_sample = false;
+            }
+            MRT_STAMP(0);
 
-                if (!scattered) {
-                    path_done = true;                                   // :349-351 -> vec3(0)
+            bool path_done = false;
+            V3 contrib = v3(0.0f, 0.0f, 0.0f);
+
+            if (depth_left == 0u) {
+                path_done = true;                                           // loop :339 not entered -> :357
+            } else {
+                // ------------------------------------------------ world_hit, shader.wgsl:314-329
+                bounces++;
+                const float a = dot3(d, d);                                 // sphere_hit :277 (same for every sphere)
+                float t_sup = 1.0e4f;                                       // :340
+                int32_t best = -1;
+                // A ray with a non-finite component makes every discriminant NaN, which the
+                // reference treats as "not < 0".  Such lanes take the literal loop below.
+                const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
+                                     __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff());
+                // Discriminant sweep + exact pass, in blocks of kBlockChunks x kChunk spheres.
+                // Sphere records are wave-uniform: they are fetched with scalar loads, 8 records (two
+                // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
+                // loads of group g+1, then run the 8 x 12 VALU ops of group g while they fly.
+                Sph8 ga, gb;
+                smem_load8(ga, sph_quads, 0u);
+                for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
+                    const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
+                    uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
+                    uint32_t c = 0;
+                    for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
+                        uint32_t bits = 0;
+                        smem_wait_then_load8(ga, gb, sph_quads, i + 8u, bits);  test8(ga, o, d, a, bits);
+                        const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
+                        smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);     test8(gb, o, d, a, bits);
+                        MRT_STAMP(1);
+                        // 16 signs in bits[15:0], sphere i at bit 15; candidate = discriminant >= 0
+                        const uint32_t m = weird ? 0u : (~bits & 0xFFFFu);
+                        masks[c * 64u] = (uint16_t)m;
+                        nz |= (m != 0u ? 1u : 0u) << c;
+                        MRT_STAMP(2);
+                    }
+                    // exact pass over this block's candidates, each lane in increasing sphere index:
+                    // every trip handles one candidate of every lane that still has one
+                    uint32_t m = 0, base = 0;
+                    while ((nz | m) != 0u) {
+                        if (m == 0u) {
+                            const uint32_t cc = (uint32_t)__builtin_ctz(nz);
+                            nz &= nz - 1u;
+                            m = masks[cc * 64u];
+                            base = blk + cc * kChunk;
+                        }
+                        const uint32_t j = (uint32_t)__builtin_clz(m) - 16u;   // sphere base + j, lowest index first
+                        m &= ~(0x8000u >> j);
+                        const uint32_t idx = base + j;
+                        exact_test(spheres[idx], idx, o, d, a, t_sup, best);
+                    }
+                }
+                // the last prefetch is never consumed, but its destination SGPRs must stay reserved
+                // until it has landed
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi));
+                if (weird) {
+                    for (uint32_t idx = 0; idx < P.n_spheres; idx++)
+                        exact_test(spheres[idx], idx, o, d, a, t_sup, best);
+                }
+                MRT_STAMP(3);
+
+                if (best < 0) {
+                    // color_sky, shader.wgsl:331-334, 343-345
+                    float t = 0.5f * d.y + 0.5f;
+                    contrib = att * v3(mixf(1.0f, 0.5f, t), mixf(1.0f, 0.7f, t), mixf(1.0f, 1.0f, t));
+                    path_done = true;
                 } else {
-                    att = att * albedo;                                 // :353
-                    o = at;
-                    d = normalize3(ndir);                               // :354
-                    depth_left--;
-                    if (depth_left == 0u) path_done = true;             // loop ends -> :357 vec3(0)
+                    // rest of sphere_hit for the winning sphere, shader.wgsl:298-309
+                    const V3 center = load_vec4_xyz(P.vec4_data, P.world.spheres.center_base_idx + best);
+                    const float radius = P.f32_data[P.world.spheres.radius_base_idx + best];
+                    const int32_t m_ty = P.i32_data[P.world.spheres.material_ty_base_idx + best];
+                    const int32_t m_idx = P.i32_data[P.world.spheres.material_idx_base_idx + best];
+                    const V3 at = o + t_sup * d;                            // ray_normalized_at :103-105
+                    V3 normal = (at - center) / radius;
+                    const bool front_face = dot3(normal, d) <= 0.0f;
+                    if (!front_face) normal = -normal;
+
+                    // dyn_material_scatter, shader.wgsl:244-252
+                    V3 albedo = v3(1.0f, 1.0f, 1.0f), ndir = d;
+                    bool scattered;
+                    if (m_ty == MRT_LAMBERTIAN) {                           // :203-216
+                        albedo = load_vec4_xyz(P.vec4_data, P.world.lambertians.albedo_base_idx + m_idx);
+                        ndir = normal + normalize3(rng_unit_ball(rng));     // unit_sphere :92-94
+                        if (dot3(ndir, ndir) == 0.0f) ndir = normal;
+                        scattered = true;
+                    } else if (m_ty == MRT_METAL) {                         // :228-242
+                        const V3 refl = reflect3(d, normal);
+                        const float fuzz = P.f32_data[P.world.metals.fuzz_base_idx + m_idx];
+                        const V3 ball = rng_unit_ball(rng);
+                        ndir = v3(refl.x + fuzz * ball.x, refl.y + fuzz * ball.y, refl.z + fuzz * ball.z);
+                        scattered = !(dot3(ndir, normal) <= 0.0f);
+                        albedo = load_vec4_xyz(P.vec4_data, P.world.metals.albedo_base_idx + m_idx);
+                    } else if (m_ty == MRT_DIELECTRIC) {                    // extension, DESIGN.md §3
+                        const float ior = P.f32_data[P.world.dielectrics.ior_base_idx + m_idx];
+                        const float ri = front_face ? (1.0f / ior) : ior;
+                        float cos_t = dot3(-d, normal);
+                        cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;
+                        const float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+                        const bool cannot_refract = (ri * sin_t) > 1.0f;
+                        float r0 = (1.0f - ri) / (1.0f + ri);
+                        r0 = r0 * r0;
+                        const float x1 = 1.0f - cos_t;
+                        const float x2 = x1 * x1; const float x4 = x2 * x2; const float x5 = x4 * x1;
+                        const float reflectance = r0 + (1.0f - r0) * x5;
+                        const float u = rng_f32(rng);                       // always exactly one draw
+                        if (cannot_refract || reflectance > u) {
+                            ndir = reflect3(d, normal);
+                        } else {
+                            const V3 perp = v3(ri * (d.x + cos_t * normal.x), ri * (d.y + cos_t * normal.y),
+                                               ri * (d.z + cos_t * normal.z));
+                            const float k = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
+                            ndir = v3(perp.x + k * normal.x, perp.y + k * normal.y, perp.z + k * normal.z);
+                        }
+                        scattered = true;
+                    } else {
+                        scattered = false;                                  // :249-251
+                    }
+
+                    if (!scattered) {
+                        path_done = true;                                   // :349-351 -> vec3(0)
+                    } else {
+                        att = att * albedo;                                 // :353
+                        o = at;
+                        d = normalize3(ndir);                               // :354
+                        depth_left--;
+                        if (depth_left == 0u) path_done = true;             // loop ends -> :357 vec3(0)
+                    }
                 }
             }
+
+            MRT_STAMP(4);
+            if (path_done) {
+                color = color + contrib;                                    // :381
+                s_done++;
+                if (s_done < spp) need_sample = true; else task_done = true;
+            }
         }
-
-        MRT_STAMP(4);
-        if (path_done) {
-            color = color + contrib;                                    // :381
-            if (started < spp) need_sample = true; else active = false;
-        }
     }
-
-    if (!PILOT && valid) {
-        const float n = (float)spp;
-        color = v3(color.x / n, color.y / n, color.z / n);              // :383
-        const float w = P.locals.framebuffer_weight;
-        const float4 q = reinterpret_cast<const float4*>(P.prev)[texel];   // framebuffer_load :366-369
-        float4 r;
-        r.x = mixf(color.x, q.x, w);                                    // :385
-        r.y = mixf(color.y, q.y, w);
-        r.z = mixf(color.z, q.z, w);
-        r.w = mixf(1.0f, q.w, w);
-        reinterpret_cast<float4*>(P.out)[texel] = r;
-    } else if (!PILOT && px < W) {
-        // padding rows of the last band of a shard: keep them defined
-        reinterpret_cast<float4*>(P.out)[texel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-
-    uint32_t t = trips;                           // the wave ran max-over-lanes trips of its loop
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o2 = __shfl_xor(t, off);
-        t = t > o2 ? t : o2;
-    }
-    if (lane == 0 && P.tile_cost) P.tile_cost[tile] = t;   // next frame's launch order
 
     if (COUNT && !PILOT) {
         unsigned long long c0 = started, c1 = bounces, c2 = rng.draws;
@@ -437,16 +486,53 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
             atomicAdd(P.counters + 0, c0);
             atomicAdd(P.counters + 1, c1);
             atomicAdd(P.counters + 2, c2);
-            atomicAdd(P.counters + 3, 64ull * t);
+            atomicAdd(P.counters + 3, 64ull * trips);
 #ifdef MRT_STAMPS
             for (int k = 0; k < 6; k++) atomicAdd(P.counters + 4 + k, (unsigned long long)phase_[k]);
             if (P.wave_log) {
-                unsigned long long* w = P.wave_log + 4ull * tile;
-                w[0] = wave_t0_; w[1] = __builtin_amdgcn_s_memrealtime(); w[2] = t; w[3] = c1;
+                unsigned long long* wl = P.wave_log + 4ull * blockIdx.x;
+                wl[0] = wave_t0_; wl[1] = __builtin_amdgcn_s_memrealtime(); wl[2] = trips; wl[3] = c1;
             }
 #endif
         }
     }
+}
+
+// After render_kernel: per 8x8 tile, one coalesced pass over the parked colour sums --
+// colour / spp blended with the previous framebuffer (shader.wgsl:383-385), whole 128-byte lines --
+// and the tile's cost (sum of its pixels' bounce-loop trips) for the next frame's queue order.
+template <bool PILOT>
+__global__ void __launch_bounds__(64) finalize_kernel(const KParams P) {
+    const uint32_t lane = threadIdx.x, tile = blockIdx.x;
+    const uint32_t W = P.locals.shape[0], H = P.locals.shape[1];
+    const uint32_t tile_x = tile % P.tiles_x, band = tile / P.tiles_x;
+    const uint32_t px = tile_x * kTileW + (lane & 7u);
+    const uint32_t py = (band * P.shard_world + P.shard_rank) * kBandRows + (lane >> 3);
+    const size_t texel = (size_t)(band * kBandRows + (lane >> 3)) * W + px;
+    uint32_t cost = 0;
+    if (px < W && py < H) {
+        const PixAcc sa = reinterpret_cast<const PixAcc*>(P.pix_acc)[texel];
+        cost = sa.cost;
+        if (!PILOT) {
+            const float n = (float)P.locals.samples_per_frame;
+            const V3 mean = v3(sa.r / n, sa.g / n, sa.b / n);                       // :383
+            const float w = P.locals.framebuffer_weight;
+            const float4 prev = reinterpret_cast<const float4*>(P.prev)[texel];        // framebuffer_load :366-369
+            float4 res;
+            res.x = mixf(mean.x, prev.x, w);                                        // :385
+            res.y = mixf(mean.y, prev.y, w);
+            res.z = mixf(mean.z, prev.z, w);
+            res.w = mixf(1.0f, prev.w, w);
+            reinterpret_cast<float4*>(P.out)[texel] = res;
+        }
+    } else if (!PILOT && px < W) {
+        reinterpret_cast<float4*>(P.out)[texel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // shard padding rows
+    }
+    // A pixel's samples form one sequential chain, so the frame's critical path is its longest
+    // pixel: tiles are ranked by their HEAVIEST pixel, not by their sum.
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o2 = __shfl_xor(cost, off); cost = cost > o2 ? cost : o2; }
+    if (lane == 0 && P.tile_cost) P.tile_cost[tile] = cost;
 }
 
 // Seed texture (Subject::new, lib.rs:389-415) generated on the device: SplitMix64 used as a
@@ -478,16 +564,31 @@ __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64
 
 }  // namespace
 
-int launch_render(const KParams& p, bool pilot, void* stream) {
-    if (p.n_tiles == 0) return 0;
-    dim3 grid(p.n_tiles), block(64);
-    if (pilot)
-        hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, (hipStream_t)stream, p);
-    else if (p.counters)
-        hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, (hipStream_t)stream, p);
+int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) {
+    if (p.n_tiles == 0 || n_waves == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(n_waves < p.n_tiles ? n_waves : p.n_tiles), block(64);
+    if (pilot) {
+        hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((finalize_kernel<true>), dim3(p.n_tiles), block, 0, st, p);
+    } else {
+        if (p.counters)
+            hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, st, p);
+        else
+            hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((finalize_kernel<false>), dim3(p.n_tiles), block, 0, st, p);
+    }
     return (int)hipGetLastError();
+}
+
+// how many waves of the render kernel one CU holds (occupancy API)
+int render_waves_per_cu(int* out) {
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false>, 64, 0);
+    *out = nb;
+    return (int)e;
 }
 
 int launch_fill_seeds(uint32_t* seeds, uint64_t seed, uint32_t width, uint32_t height,

@@ -34,14 +34,20 @@ struct KParams {
     const float* prev;          // r_framebuffer: local_rows x W x rgba
     float* out;                 // render target
     unsigned long long* counters;  // 4 x u64 (mrt_counters) or null
-    const uint32_t* tile_order; // n_tiles tile ids, heaviest first, or null = identity
-    uint32_t* tile_cost;        // n_tiles: loop trips of each tile's wave in this frame, or null
-    uint32_t tiles_x, n_tiles;  // tiles per band row; tiles in this shard (= grid size)
+    // the frame's tile queue: persistent waves pull tiles tile_order[atomicAdd(tile_queue, 1)]
+    const uint32_t* tile_order; // n_tiles tile ids, heaviest first (tile_order.hip), or null = index order
+    uint32_t* tile_queue;       // one u32, zeroed before every launch
+    uint32_t tiles_x, n_tiles;  // tiles per band row; tiles in this shard
+    uint32_t pilot_spp;         // samples per pixel of the cost-estimating pilot launch
+    uint32_t* tile_cost;        // n_tiles: sum of its pixels' loop trips in this frame, or null
+    void* pix_acc;              // per local pixel: colour sum of the frame + its cost (16 B), render -> finalize
     unsigned long long* wave_log;  // diagnostic (-DMRT_STAMPS builds): 4 x u64 per wave, or null
 };
 
 // host-callable launchers (kernels.hip)
-int launch_render(const KParams& p, bool pilot, void* stream);
+// render (or pilot) launch = queue reset + n_waves persistent waves + the per-tile finalize pass
+int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream);
+int render_waves_per_cu(int* out);
 // tile_order.hip: order[] = tile ids sorted by cost[] descending (bucket sort; ties in any order).
 // scratch: 1024 u32.
 int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, uint32_t n_tiles, void* stream);

@@ -1,8 +1,10 @@
-// Launch-order kernels: sort this shard's 8x8 tiles by the cost (bounce-loop trips) their
-// waves had in the previous frame -- or in a 1-spp pilot pass before the first frame --
-// heaviest first.  No reference counterpart: the reference issues one full-screen draw
-// (raytracer/src/lib.rs:262-267) and leaves scheduling to the GPU.  The order only affects
-// WHEN a tile runs, never its pixels (every pixel owns its RNG stream and output texel).
+// Tile-queue order: sort this shard's 8x8 tiles by the cost (bounce-loop trips of their pixels)
+// measured in the previous frame -- or in a small pilot pass before the first frame -- heaviest
+// first.  render_kernel's persistent waves pull tiles from the queue in that order, so the
+// lightest tiles are the last ones anybody starts.  No reference counterpart: the reference
+// issues one full-screen draw (raytracer/src/lib.rs:262-267) and leaves scheduling to the GPU.
+// The order only affects WHICH wave renders a tile and when, never its pixels (every pixel owns
+// its RNG stream and output texel).
 //
 // A bucket sort is enough (ties may land in any order): key = 5-bit exponent | 5-bit
 // mantissa of the cost, 1024 buckets, three tiny launches.

@@ -4,12 +4,17 @@ import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import myraytracer_amd as M
 
-def run(scene, w, h, spp, depth=50, frames=2):
+def run(scene, w, h, spp, depth=50, frames=2, shard=None):
     if scene == "cover-glass": sp, cam = M.scene_cover(1, True)
     elif scene == "cover": sp, cam = M.scene_cover(1, False)
     elif scene == "stress": sp, cam = M.scene_stress(1, 100)
     else: sp, cam = M.scene_default(), None
-    with M.State(M.Args(w, h, spp, depth, 1.0), seed=1) as st:
+    with M.State(M.Args(w, h, spp, depth, 1.0), seed=1, shard=shard) as st:
+        sched = os.environ.get("MRT_SCHED")        # "pilot,waves_per_cu"
+        if sched:
+            from myraytracer_amd import _lib
+            a_ = [int(x) for x in sched.split(",")]
+            assert _lib.load().mrt_debug_set_schedule(st._ctx, a_[0], a_[1]) == 0
         st.set_world(sp)
         if cam is not None: st.set_camera(cam)
         st.render(1); st.sync()
@@ -21,8 +26,9 @@ def run(scene, w, h, spp, depth=50, frames=2):
         n = len(sp)
         ms_avg = sum(ms) / len(ms)
         tests = d["world_hit_calls"] * n
-        print(json.dumps({"scene": scene, "n": n, "w": w, "h": h, "spp": spp, "ms": round(ms_avg, 3),
-                          "Msamples/s": round(w * h * spp / ms_avg * 1e-3, 1),
+        share = 1.0 / shard[1] if shard else 1.0
+        print(json.dumps({"scene": scene, "n": n, "w": w, "h": h, "spp": spp, "shard": shard, "sched": os.environ.get("MRT_SCHED"), "ms": round(ms_avg, 3),
+                          "Msamples/s": round(w * h * spp * share / ms_avg * 1e-3, 1),
                           "bounces/sample": round(d["world_hit_calls"] / d["samples"], 3),
                           "lane_util": round(d["world_hit_calls"] / max(1, d["lane_slots"]), 4),
                           "Gtests/s": round(tests / ms_avg * 1e-6, 1),
@@ -31,4 +37,5 @@ def run(scene, w, h, spp, depth=50, frames=2):
 if __name__ == "__main__":
     a = sys.argv[1:]
     run(a[0] if a else "cover-glass", int(a[1]) if len(a) > 1 else 1920, int(a[2]) if len(a) > 2 else 1080,
-        int(a[3]) if len(a) > 3 else 32, int(a[4]) if len(a) > 4 else 50)
+        int(a[3]) if len(a) > 3 else 32, int(a[4]) if len(a) > 4 else 50,
+        shard=(int(a[5]), int(a[6])) if len(a) > 6 else None)

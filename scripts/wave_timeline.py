@@ -27,7 +27,18 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
         print(f"{i*5:3d}%  resident waves {resident:6d}")
     dur = (t1 - t0)
     print("wave duration ticks: mean %.0f  p50 %.0f  p99 %.0f  max %.0f" % (dur.mean(), np.percentile(dur, 50), np.percentile(dur, 99), dur.max()))
-    late = np.argsort(t1)[-10:]
-    tw = (w + 7) // 8
-    for i in late:
-        print("late tile x=%d band=%d trips=%d start=%.2f end=%.2f" % (i % tw, i // tw, trips[i], t0[i] / total, t1[i] / total))
+    print("starts: p50 %.3f p90 %.3f max %.3f of span; ends: p10 %.3f p50 %.3f p90 %.3f" % (
+        np.percentile(t0, 50) / total, np.percentile(t0, 90) / total, t0.max() / total,
+        np.percentile(t1, 10) / total, np.percentile(t1, 50) / total, np.percentile(t1, 90) / total))
+    print("trips per wave: min %d p50 %d max %d" % (trips.min(), np.percentile(trips, 50), trips.max()))
+    _, _, rows, width = st.shard_info()
+    pc = np.zeros(rows * width, np.uint32)
+    L.mrt_debug_read_pixel_costs(st._ctx, pc.ctypes.data, pc.size)
+    pc = pc.reshape(rows, width)
+    print("pixel cost (trips): mean %.1f p50 %d p99 %d p99.9 %d max %d ; total/6144/64 = %.0f trips per wave slot" % (
+        pc.mean(), np.percentile(pc, 50), np.percentile(pc, 99), np.percentile(pc, 99.9), pc.max(), pc.sum() / 6144 / 64))
+    ys, xs = np.unravel_index(np.argsort(pc, axis=None)[-5:], pc.shape)
+    print("heaviest pixels (x,y,cost):", [(int(x), int(y), int(pc[y, x])) for x, y in zip(xs, ys)])
+    last = np.argsort(t1)[-3:]
+    for i in last:
+        print("last waves: trips=%d start=%.3f end=%.3f" % (trips[i], t0[i] / total, t1[i] / total))

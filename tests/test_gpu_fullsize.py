@@ -35,7 +35,9 @@ def test_c3_full_resolution_properties(mrt, oracle):
     sc, cam = mrt.scene_cover(1, True)
     a, ca, _ = gpu_render(mrt, sc, cam, 1920, 1080, 8, 50, 1)
     b, cb, _ = gpu_render(mrt, sc, cam, 1920, 1080, 8, 50, 1)
-    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and ca == cb            # deterministic
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))                       # deterministic pixels
+    for k in ("samples", "world_hit_calls", "rng_draws"):                               # lane_slots depends on the schedule
+        assert ca[k] == cb[k]
     rows = [3, 540, 1000]
     ref = _oracle_rows(oracle, sc, cam, 1920, 1080, 8, 50, 1, rows)
     for y in rows:
