@@ -53,15 +53,25 @@ struct mrt_ctx {
     float* d_fb[2] = {nullptr, nullptr};   // [target, secondary] ping-pong (lib.rs:505-543)
     int target = 0;                        // index of the buffer the NEXT redraw writes
     unsigned long long* d_counters = nullptr;
-    // tile queue (tile_order.hip): tile costs measured in frame n order the queue of frame n+1
-    uint32_t* d_tile_cost = nullptr;
-    uint32_t* d_tile_order = nullptr;
-    uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter
-    void* d_pix_acc = nullptr;             // per-pixel colour sums + costs, render -> finalize
+    // Two frames may be in flight: frame n's render kernel (sort, pilot) runs on side stream
+    // n % 2 and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
+    // on the caller's stream.  The next frame's heavy tiles thus start while this frame's last
+    // pixels drain (a pixel is one sequential chain, so every frame ends on a thinning chip).
+    struct FrameSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t render_done = nullptr, finalize_done = nullptr;
+        void* d_pix_acc = nullptr;             // per-pixel colour sums + costs, render -> finalize
+        uint32_t* d_tile_cost = nullptr;       // written by this slot's finalize, orders its next queue
+        uint32_t* d_tile_order = nullptr;
+        uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter
+        bool cost_valid = false;               // d_tile_cost holds a usable estimate for the current scene
+    } slot[2];
+    hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
+    bool inputs_dirty = true;
+    uint64_t frame_seq = 0;
     uint32_t tiles_x = 0, n_tiles = 0, n_waves = 0;
     uint32_t pilot_spp = 2;
     int waves_per_cu_override = 0;
-    bool cost_valid = false;               // d_tile_cost holds a usable estimate for the current scene
     bool lpt_enabled = true;
     unsigned long long* d_wave_log = nullptr;   // diagnostic, see mrt_debug_wave_log
     size_t wave_log_waves = 0;
@@ -105,14 +115,16 @@ void free_frame_buffers(mrt_ctx* c) {
     if (c->d_seeds) (void)hipFree(c->d_seeds);
     if (c->d_fb[0]) (void)hipFree(c->d_fb[0]);
     if (c->d_fb[1]) (void)hipFree(c->d_fb[1]);
-    if (c->d_tile_cost) (void)hipFree(c->d_tile_cost);
-    if (c->d_tile_order) (void)hipFree(c->d_tile_order);
-    if (c->d_sort_scratch) (void)hipFree(c->d_sort_scratch);
-    if (c->d_pix_acc) (void)hipFree(c->d_pix_acc);
+    for (auto& S : c->slot) {
+        if (S.d_tile_cost) (void)hipFree(S.d_tile_cost);
+        if (S.d_tile_order) (void)hipFree(S.d_tile_order);
+        if (S.d_sort_scratch) (void)hipFree(S.d_sort_scratch);
+        if (S.d_pix_acc) (void)hipFree(S.d_pix_acc);
+        S.d_tile_cost = S.d_tile_order = S.d_sort_scratch = nullptr;
+        S.d_pix_acc = nullptr;
+        S.cost_valid = false;
+    }
     c->d_seeds = nullptr; c->d_fb[0] = c->d_fb[1] = nullptr;
-    c->d_tile_cost = c->d_tile_order = c->d_sort_scratch = nullptr;
-    c->d_pix_acc = nullptr;
-    c->cost_valid = false;
 }
 
 void free_world(mrt_ctx* c) {
@@ -137,11 +149,15 @@ int alloc_frame_buffers(mrt_ctx* c) {
     HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, n * 4 * sizeof(float), c->stream));
     c->tiles_x = (c->args.width + mrt::kTileW - 1) / mrt::kTileW;
     c->n_tiles = c->tiles_x * c->local_bands;
-    HIP_TRY(c, hipMalloc(&c->d_tile_cost, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&c->d_tile_order, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&c->d_sort_scratch, (1024 + 16) * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&c->d_pix_acc, (n ? n : 1) * 16));
-    HIP_TRY(c, hipMemsetAsync(c->d_pix_acc, 0, (n ? n : 1) * 16, c->stream));
+    for (auto& S : c->slot) {
+        HIP_TRY(c, hipMalloc(&S.d_tile_cost, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&S.d_tile_order, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&S.d_sort_scratch, (1024 + 16) * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&S.d_pix_acc, (n ? n : 1) * 16));
+        HIP_TRY(c, hipMemsetAsync(S.d_pix_acc, 0, (n ? n : 1) * 16, c->stream));
+        S.cost_valid = false;
+    }
+    c->inputs_dirty = true;
     // as many persistent single-wave workgroups as the chip holds
     {
         hipDeviceProp_t prop;
@@ -178,6 +194,15 @@ uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
 }
 
 bool finite_in_range(float v, float lim) { return std::isfinite(v) && std::fabs(v) <= lim; }
+
+// wait for everything this context has in flight (caller's stream and both side streams)
+hipError_t sync_all(mrt_ctx* c) {
+    hipError_t e = hipSuccess, r;
+    for (auto& S : c->slot)
+        if (S.stream && (r = hipStreamSynchronize(S.stream)) != hipSuccess) e = r;
+    if (c->stream && (r = hipStreamSynchronize(c->stream)) != hipSuccess) e = r;
+    return e;
+}
 
 }  // namespace
 
@@ -350,6 +375,11 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(MRT_ERR_HIP); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(MRT_ERR_HIP); }
     c->stream = c->own_stream;
+    for (auto& S : c->slot)
+        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&S.render_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.finalize_done, hipEventDisableTiming) != hipSuccess) { c->err = "side stream creation failed"; return bail(MRT_ERR_HIP); }
+    if (hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
     for (uint32_t i = 0; i < mrt_ctx::kEventRing; i++)
         if (hipEventCreate(&c->ev_start[i]) != hipSuccess || hipEventCreate(&c->ev_stop[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
     if (hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
@@ -363,8 +393,14 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
 void mrt_destroy(mrt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     free_frame_buffers(c);
+    for (auto& S : c->slot) {
+        if (S.render_done) (void)hipEventDestroy(S.render_done);
+        if (S.finalize_done) (void)hipEventDestroy(S.finalize_done);
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+    }
+    if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
     free_world(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_wave_log) (void)hipFree(c->d_wave_log);
@@ -381,7 +417,7 @@ int mrt_set_shard(mrt_ctx* c, uint32_t rank, uint32_t world) {
     if (world == 0 || rank >= world) return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_shard: rank %u of %u", rank, world);
     if (c->frames_done != 0) return fail(c, MRT_ERR_STATE, "mrt_set_shard: frames already rendered; call mrt_reset first");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     c->shard_rank = rank; c->shard_world = world;
     return alloc_frame_buffers(c);
 }
@@ -389,8 +425,9 @@ int mrt_set_shard(mrt_ctx* c, uint32_t rank, uint32_t world) {
 int mrt_set_stream(mrt_ctx* c, void* s) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->inputs_dirty = true;
     return MRT_OK;
 }
 
@@ -424,7 +461,7 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
             return fail(c, MRT_ERR_BAD_SCENE, "sphere %lld: material index %d out of range for type %d", (long long)i, mi, ty);
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     free_world(c);
 
     const uint32_t n_padded = (uint32_t)((n + mrt::kChunk - 1) / mrt::kChunk * mrt::kChunk);
@@ -447,7 +484,8 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     HIP_TRY(c, upload((void**)&c->d_vec4, vec4, n_vec4 * 4 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
-    c->cost_valid = false;
+    c->slot[0].cost_valid = c->slot[1].cost_valid = false;
+    c->inputs_dirty = true;
     c->world = *w;
     c->n_spheres = (uint32_t)n;
     c->n_padded = n_padded;
@@ -472,7 +510,7 @@ int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
     int st = mrt_camera_derive(cam, &raw);
     if (st != MRT_OK) return fail(c, st, "mrt_set_camera: degenerate or invalid camera");
     c->camera = *cam; c->cam_raw = raw;
-    c->cost_valid = false;
+    c->slot[0].cost_valid = c->slot[1].cost_valid = false;
     return MRT_OK;
 }
 
@@ -508,6 +546,8 @@ int mrt_set_seeds(mrt_ctx* c, const uint32_t* seeds, size_t n_u32) {
     if (!c || !seeds) return MRT_ERR_INVALID_ARG;
     if (n_u32 != (size_t)c->args.width * c->args.height * 4) return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_seeds: expected W*H*4 u32");
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, sync_all(c));
+    c->inputs_dirty = true;
     return copy_rows(c, c->d_seeds, const_cast<uint32_t*>(seeds), 16, true);
 }
 
@@ -542,33 +582,49 @@ int mrt_redraw(mrt_ctx* c) {
     p.counters = c->d_counters;
     p.wave_log = c->d_wave_log;
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
-    p.tile_queue = c->d_sort_scratch + 1024;
-    p.tile_order = nullptr;
     p.pilot_spp = c->pilot_spp;
-    p.tile_cost = c->d_tile_cost;
-    p.pix_acc = c->d_pix_acc;
-    // The tile queue is ordered by the previous frame's per-tile cost, heaviest first; before
-    // the first frame of a scene a small pilot launch (no output) provides the estimate when
-    // the frame is long enough to pay for it.  Without an estimate: index order.
+    mrt_ctx::FrameSlot& S = c->slot[c->frame_seq & 1u];
+    p.tile_queue = S.d_sort_scratch + 1024;
+    p.tile_order = nullptr;
+    p.tile_cost = S.d_tile_cost;
+    p.pix_acc = S.d_pix_acc;
+    // side stream: wait for the scene / seeds uploads and for this slot's previous frame (n-2) to
+    // have been finalized (its colour sums and tile costs are about to be overwritten / used)
+    if (c->inputs_dirty) {
+        HIP_TRY(c, hipEventRecord(c->ev_inputs, c->stream));
+        c->inputs_dirty = false;
+    }
+    HIP_TRY(c, hipStreamWaitEvent(S.stream, c->ev_inputs, 0));
+    HIP_TRY(c, hipStreamWaitEvent(S.stream, S.finalize_done, 0));
+    // The tile queue is ordered by the per-tile cost this slot measured two frames ago, heaviest
+    // first; before the slot's first frame of a scene a small pilot launch (no output) provides
+    // the estimate when the frame is long enough to pay for it.  Without an estimate: index order.
     if (c->lpt_enabled) {
-        if (!c->cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
-            int pe = mrt::launch_render(p, true, c->n_waves, c->stream);
+        if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
+            int pe = mrt::launch_render(p, true, c->n_waves, S.stream);
             if (pe) return fail(c, MRT_ERR_HIP, "pilot launch failed: %s", hipGetErrorString((hipError_t)pe));
-            c->cost_valid = true;
+            S.cost_valid = true;
         }
-        if (c->cost_valid) {
-            int se = mrt::launch_sort_tiles(c->d_tile_cost, c->d_tile_order, c->d_sort_scratch, c->n_tiles, c->stream);
+        if (S.cost_valid) {
+            int se = mrt::launch_sort_tiles(S.d_tile_cost, S.d_tile_order, S.d_sort_scratch, c->n_tiles, S.stream);
             if (se) return fail(c, MRT_ERR_HIP, "tile sort launch failed: %s", hipGetErrorString((hipError_t)se));
-            p.tile_order = c->d_tile_order;
+            p.tile_order = S.d_tile_order;
         }
     }
-    const uint32_t slot = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
-    HIP_TRY(c, hipEventRecord(c->ev_start[slot], c->stream));
-    int e = mrt::launch_render(p, false, c->n_waves, c->stream);
+    const uint32_t ev = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
+    HIP_TRY(c, hipEventRecord(c->ev_start[ev], S.stream));
+    int e = mrt::launch_render(p, false, c->n_waves, S.stream);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
-    HIP_TRY(c, hipEventRecord(c->ev_stop[slot], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_stop[ev], S.stream));
+    HIP_TRY(c, hipEventRecord(S.render_done, S.stream));
     c->timed_frames++;
-    c->cost_valid = true;
+    // caller's stream: blend into the accumulated framebuffer (shader.wgsl:383-385) once the render is done
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, S.render_done, 0));
+    int fe = mrt::launch_finalize(p, c->stream);
+    if (fe) return fail(c, MRT_ERR_HIP, "finalize launch failed: %s", hipGetErrorString((hipError_t)fe));
+    HIP_TRY(c, hipEventRecord(S.finalize_done, c->stream));
+    S.cost_valid = true;
+    c->frame_seq++;
 
     c->target ^= 1;                                                       // framebuffers.swap(), lib.rs:299
     if (c->frames_done != UINT32_MAX) c->frames_done++;                   // saturating_add, lib.rs:300
@@ -593,7 +649,8 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
     if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_read_pixel_costs: need %zu", n);
     HIP_TRY(c, hipSetDevice(c->device));
     std::vector<uint32_t> tmp(n * 4);
-    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, sync_all(c));
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->slot[(c->frame_seq + 1u) & 1u].d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < n; i++) out[i] = tmp[4 * i + 3];
     return MRT_OK;
@@ -611,7 +668,7 @@ int mrt_debug_set_tile_sort(mrt_ctx* c, int enabled) {
 int mrt_debug_set_schedule(mrt_ctx* c, uint32_t pilot_spp, int waves_per_cu) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     c->pilot_spp = pilot_spp ? pilot_spp : 1;
     c->waves_per_cu_override = waves_per_cu;
     const uint32_t frames = c->frames_done;
@@ -622,13 +679,14 @@ int mrt_debug_set_schedule(mrt_ctx* c, uint32_t pilot_spp, int waves_per_cu) {
 int mrt_sync(mrt_ctx* c) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     return MRT_OK;
 }
 
 int mrt_reset(mrt_ctx* c) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, sync_all(c));
     const size_t bytes = local_texels(c) * 4 * sizeof(float);
     HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, bytes, c->stream));

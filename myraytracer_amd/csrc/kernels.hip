@@ -564,6 +564,7 @@ __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64
 
 }  // namespace
 
+// queue reset + the persistent render waves (pilot: + its cost-only finalize) on `stream`
 int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) {
     if (p.n_tiles == 0 || n_waves == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
@@ -573,13 +574,18 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
     if (pilot) {
         hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, st, p);
         hipLaunchKernelGGL((finalize_kernel<true>), dim3(p.n_tiles), block, 0, st, p);
+    } else if (p.counters) {
+        hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, st, p);
     } else {
-        if (p.counters)
-            hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, st, p);
-        else
-            hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, st, p);
-        hipLaunchKernelGGL((finalize_kernel<false>), dim3(p.n_tiles), block, 0, st, p);
+        hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, st, p);
     }
+    return (int)hipGetLastError();
+}
+
+// colour sums -> framebuffer (+ per-tile costs), one wave per 8x8 tile
+int launch_finalize(const KParams& p, void* stream) {
+    if (p.n_tiles == 0) return 0;
+    hipLaunchKernelGGL((finalize_kernel<false>), dim3(p.n_tiles), dim3(64), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

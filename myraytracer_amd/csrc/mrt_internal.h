@@ -45,8 +45,10 @@ struct KParams {
 };
 
 // host-callable launchers (kernels.hip)
-// render (or pilot) launch = queue reset + n_waves persistent waves + the per-tile finalize pass
+// queue reset + n_waves persistent render waves (a pilot launch also runs its cost-only finalize)
 int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream);
+// the per-tile finalize pass of a rendered frame: colour sums -> framebuffer, tile costs
+int launch_finalize(const KParams& p, void* stream);
 int render_waves_per_cu(int* out);
 // tile_order.hip: order[] = tile ids sorted by cost[] descending (bucket sort; ties in any order).
 // scratch: 1024 u32.
