@@ -26,9 +26,21 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t cost) {
     return key < kBuckets ? key : kBuckets - 1u;
 }
 
+// Equal costs are common (every pure-sky tile costs exactly spp trips per pixel), so global atomics per
+// tile would pile up on one address: both passes first combine a block's 1024 tiles in LDS.
+constexpr uint32_t kTilesPerBlock = 1024;
+
 __global__ void __launch_bounds__(256) tile_hist_kernel(const uint32_t* __restrict__ cost, uint32_t* hist, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+    __shared__ uint32_t local[kBuckets];
+    for (uint32_t k = threadIdx.x; k < kBuckets; k += 256) local[k] = 0;
+    __syncthreads();
+    for (uint32_t j = 0; j < kTilesPerBlock / 256; j++) {
+        const uint32_t i = blockIdx.x * kTilesPerBlock + j * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&local[cost_bucket(cost[i])], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kBuckets; k += 256)
+        if (local[k]) atomicAdd(&hist[k], local[k]);
 }
 
 // one block of 1024 threads: hist[b] <- number of tiles in heavier buckets (descending exclusive scan)
@@ -48,8 +60,23 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(uint32_t* hist) {
 
 __global__ void __launch_bounds__(256) tile_scatter_kernel(const uint32_t* __restrict__ cost, uint32_t* offsets,
                                                            uint32_t* __restrict__ order, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[atomicAdd(&offsets[cost_bucket(cost[i])], 1u)] = i;
+    __shared__ uint32_t local[kBuckets];      // count, then this block's base offset, per bucket
+    for (uint32_t k = threadIdx.x; k < kBuckets; k += 256) local[k] = 0;
+    __syncthreads();
+    uint32_t bucket[kTilesPerBlock / 256], rank[kTilesPerBlock / 256];
+    for (uint32_t j = 0; j < kTilesPerBlock / 256; j++) {
+        const uint32_t i = blockIdx.x * kTilesPerBlock + j * 256 + threadIdx.x;
+        bucket[j] = 0; rank[j] = 0;
+        if (i < n) { bucket[j] = cost_bucket(cost[i]); rank[j] = atomicAdd(&local[bucket[j]], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kBuckets; k += 256)
+        if (local[k]) local[k] = atomicAdd(&offsets[k], local[k]);     // reserve this block's range
+    __syncthreads();
+    for (uint32_t j = 0; j < kTilesPerBlock / 256; j++) {
+        const uint32_t i = blockIdx.x * kTilesPerBlock + j * 256 + threadIdx.x;
+        if (i < n) order[local[bucket[j]] + rank[j]] = i;
+    }
 }
 
 }  // namespace
@@ -59,7 +86,7 @@ int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, 
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(scratch, 0, kBuckets * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
-    const uint32_t blocks = (n_tiles + 255u) / 256u;
+    const uint32_t blocks = (n_tiles + kTilesPerBlock - 1u) / kTilesPerBlock;
     hipLaunchKernelGGL(tile_hist_kernel, dim3(blocks), dim3(256), 0, st, cost, scratch, n_tiles);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, scratch);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, st, cost, scratch, order, n_tiles);

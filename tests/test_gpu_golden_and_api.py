@@ -203,3 +203,52 @@ def test_empty_world_is_all_sky(mrt, oracle):
     ref = oracle_render(oracle, sc, None, 32, 18, 2, 8, 1)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     assert c["world_hit_calls"] == 32 * 18 * 2
+
+
+def test_pipelined_frames_match_stepwise_reads(mrt, oracle):
+    """Two frames are in flight inside mrt_redraw (side streams); reading the framebuffer after every
+    frame, after every other frame, or only at the end must give the same accumulation."""
+    sc = mrt.scene_default()
+    ref = oracle_render(oracle, sc, None, 64, 40, 16, 8, 21, frames=6)
+    with mrt.State(mrt.Args(64, 40, 16, 8), seed=21) as st:
+        st.set_world(sc)
+        seen = []
+        for f in range(6):
+            st.redraw()
+            if f % 2 == 1:
+                seen.append(st.read_framebuffer())
+        assert np.array_equal(seen[-1].view(np.uint32), ref.view(np.uint32))
+    with mrt.State(mrt.Args(64, 40, 16, 8), seed=21) as st:
+        st.set_world(sc)
+        st.render(6)
+        assert np.array_equal(st.read_framebuffer().view(np.uint32), ref.view(np.uint32))
+        assert st.read_counters()["samples"] == 64 * 40 * 16 * 6
+
+
+def test_scene_change_between_frames(mrt, oracle):
+    """Uploading a new scene while frames are in flight waits for them; the accumulation continues."""
+    a, cam = mrt.scene_cover(1, True)
+    b, _ = mrt.scene_cover(2, True)
+    with mrt.State(mrt.Args(48, 32, 16, 20), seed=3) as st:
+        st.set_world(a)
+        st.set_camera(cam)
+        st.render(2)
+        st.set_world(b)
+        st.render(2)
+        got = st.read_framebuffer()
+    from common import to_oracle_camera, to_oracle_spheres
+    seeds = oracle.fill_seeds(3, 48, 32)
+    fb = np.zeros((32, 48, 4), np.float32)
+    for f in range(4):
+        pw = oracle.pack_world(to_oracle_spheres(oracle, a if f < 2 else b))
+        fb = oracle.render_frame(48, 32, 16, 20, pw, to_oracle_camera(oracle, cam), seeds, oracle.frame_shuffle(3, f),
+                                 oracle.frame_weight(f, 1.0), fb)
+    assert np.array_equal(got.view(np.uint32), fb.view(np.uint32))
+
+
+def test_low_spp_frames_skip_the_pilot_and_still_match(mrt, oracle):
+    """samples_per_frame = 1 (the reference's default): no pilot pass, index-order queue on the first frames."""
+    sc, cam = mrt.scene_cover(1, False)
+    ref = oracle_render(oracle, sc, cam, 80, 48, 1, 50, 5, frames=5)
+    got, _, _ = gpu_render(mrt, sc, cam, 80, 48, 1, 50, 5, frames=5)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
