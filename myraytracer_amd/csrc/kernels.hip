@@ -1,23 +1,23 @@
 // HIP kernels for gfx950 (MI355X): the per-pixel render loop of zetanumbers/myraytracer
 // (raytracer/src/shader.wgsl fs_main and everything it calls), rebuilt for CDNA4.
 //
-// Shape of the kernel (see DESIGN.md for the measurements behind each choice):
+// Shape of the kernels (DESIGN.md §4 has the measurements behind each choice):
 //   * one lane = one pixel for the whole frame, as in the fragment shader, so the
 //     reference's one-Xoshiro128+-stream-per-pixel draw order is preserved exactly;
 //   * the sample loop and the bounce loop (shader.wgsl:378, :339) are flattened into ONE
 //     per-lane state machine: every trip of the wave's loop is one `world_hit` for every
-//     live lane, whichever sample / bounce that lane is on, so a lane whose path ended
-//     starts its next sample immediately instead of idling until the wave's longest path
-//     ends;
+//     live lane, whichever sample / bounce that lane is on;
 //   * `world_hit` (shader.wgsl:314-329) is split into a branch-free discriminant sweep
 //     over all spheres -- sphere records are wave-uniform, so they are fetched by scalar
 //     loads into SGPRs (no LDS, no VGPRs, no per-lane bandwidth) and each test costs 11
 //     fp32 VALU ops + 1 v_alignbit that shifts the sign of the discriminant into a
-//     per-lane 32-sphere bitmask -- and an exact pass over the few spheres whose
+//     per-lane 16-sphere bitmask -- and an exact pass over the few spheres whose
 //     discriminant was non-negative, in index order, with the reference's sqrt / divide /
-//     range tests (shader.wgsl:286-296).  Candidate indices wait in an LDS list per lane.
-//   * one coalesced RGBA32F store per pixel per frame; the 8x8 wave tile writes whole
-//     128-byte lines.
+//     range tests (shader.wgsl:286-296).  The masks wait in LDS;
+//   * persistent waves pull 8x8 tiles from one global heaviest-first queue and a lane that
+//     finishes its pixel takes the next waiting one (render_kernel);
+//   * finalize_kernel turns the per-pixel colour sums into the framebuffer: one coalesced
+//     RGBA32F store per pixel per frame, whole 128-byte lines per 8x8 tile.
 //
 // Arithmetic follows the "MRT-F32" rules: fma only where written, no
 // contraction (-ffp-contract=off), correctly rounded sqrt and divide (hipcc default).

@@ -252,3 +252,19 @@ def test_low_spp_frames_skip_the_pilot_and_still_match(mrt, oracle):
     ref = oracle_render(oracle, sc, cam, 80, 48, 1, 50, 5, frames=5)
     got, _, _ = gpu_render(mrt, sc, cam, 80, 48, 1, 50, 5, frames=5)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+
+
+def test_degenerate_rays_follow_the_reference_nan_semantics(mrt, oracle):
+    """A metal with an absurd fuzz overflows `dir` so that normalize() returns the zero vector; the next
+    sphere tests then have a == 0, t = -0/0 = NaN, and the reference's comparisons (`t < t_min || t_sup <= t`
+    false for NaN, shader.wgsl:291-296) ACCEPT every sphere, after which the ray origin is NaN.  The kernel's
+    non-finite-ray path must reproduce all of it bit for bit, RNG draw count included."""
+    sc = mrt.scene_default()
+    sc["param"][2] = 1e30
+    sc["param"][3] = 3e38
+    cnt = oracle.Counters()
+    ref = oracle_render(oracle, sc, None, 64, 36, 8, 12, 4, counters=cnt)
+    got, c, _ = gpu_render(mrt, sc, None, 64, 36, 8, 12, 4)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    assert c["rng_draws"] == cnt.rng_draws and c["world_hit_calls"] == cnt.world_hit_calls
+    assert cnt.paths_exhausted > 1000          # the degenerate chains really happened
