@@ -79,8 +79,8 @@ def cpu_baseline(spheres, cam, width, height, depth, seed, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=0, help="override the workload (not a valid headline run)")
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
@@ -174,7 +174,9 @@ def main():
         n_spheres = len(spheres)
         # roofline of the dominant (only) kernel, per launch on one GPU
         local_px = float(width) * height / world
-        alg_bytes = local_px * (16 + 16 + 16) + ((n_spheres + 31) // 32 * 32) * 16 + n_spheres * 28   # seeds + prev + out; scene once
+        # render_kernel per launch: 16 B seed in + 16 B colour sum out per pixel, scene once.  (The blend
+        # with the previous framebuffer -- 48 B per pixel -- is finalize_kernel, an HBM-bound ~25 us pass.)
+        alg_bytes = local_px * (16 + 16) + ((n_spheres + 15) // 16 * 16) * 16 + n_spheres * 28
         achieved = alg_bytes / (kernel_ms_max * 1e-3) * 1e-9
         traffic = None
         try:

@@ -34,6 +34,8 @@ if "GRBM_GUI_ACTIVE" in vals:
     out["derived"] = {"kernel_cycles": cyc}
     if "SQ_INSTS_VALU" in vals:
         out["derived"]["valu_issue_utilisation_at_2cyc_per_inst"] = vals["SQ_INSTS_VALU"] * 2.0 / (1024 * cyc)
+        out["derived"]["valu_note"] = ("per-kernel cycles: launches of consecutive frames overlap, so this under-states the chip's "
+                                       "utilisation; over wall time per frame it is SQ_INSTS_VALU*2/(1024*ms_per_step*clock)")
     if "SQ_THREAD_CYCLES_VALU" in vals and "SQ_ACTIVE_INST_VALU" in vals:
         out["derived"]["valu_thread_utilisation"] = vals["SQ_THREAD_CYCLES_VALU"] / (vals["SQ_ACTIVE_INST_VALU"] * 64.0)
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
