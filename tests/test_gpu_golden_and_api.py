@@ -268,3 +268,22 @@ def test_degenerate_rays_follow_the_reference_nan_semantics(mrt, oracle):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
     assert c["rng_draws"] == cnt.rng_draws and c["world_hit_calls"] == cnt.world_hit_calls
     assert cnt.paths_exhausted > 1000          # the degenerate chains really happened
+
+
+def test_native_runner_cli(mrt, tmp_path):
+    """The headless counterpart of native-runner (main.rs:20-31): same five flags, writes an image."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "myraytracer_amd", "lib", "native_runner")
+    out = str(tmp_path / "o.pfm")
+    r = subprocess.run([exe, "--width", "64", "--height", "36", "--samples-per-frame", "4", "--ray-depth", "8",
+                        "--max-framebuffer-weight", "1.0", "--frames", "2", "--seed", "1", "--out", out],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(out, "rb").read()
+    head = b"PF\n64 36\n-1.0\n"
+    assert raw.startswith(head)
+    img = np.frombuffer(raw[len(head):], np.float32).reshape(36, 64, 3)
+    ref, _, _ = gpu_render(mrt, mrt.scene_default(), None, 64, 36, 4, 8, 1, frames=2)
+    assert np.array_equal(img, ref[..., :3])
+    r = subprocess.run([exe, "--bogus", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2
