@@ -11,9 +11,10 @@ samples_per_frame spp over the whole image, blended into the accumulated framebu
 
 Workload (BASELINE.json): the metric is quoted on "1920x1080 random-spheres" = configs[2]
 (C3: RTIOW cover scene with Dielectric + defocus blur, 1920x1080, 512 spp, depth 50).
-Multi-GPU is weak scaling towards configs[3] (C4 = 8 x C3's samples at 8 GPUs):
-N=1 1920x1080x512, N=2 1920x1080x1024, N=4 3840x2160x512, N=8 3840x2160x1024; the image
-is tile-sharded in interleaved 8-row bands, every rank renders (1/N) of it.
+Multi-GPU is weak scaling towards configs[3] (C4 = 8 x C3's samples at 8 GPUs): the same scene
+and camera with N x C3's samples -- N=1 1920x1080x512, N=2 2716x1528x512 (2.001 x the pixels, same
+16:9 framing), N=4 3840x2160x512, N=8 3840x2160x1024 (= C4); the image is tile-sharded in
+interleaved 8-row bands, every rank renders (1/N) of it.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, as
 north_star asks; this path is VALU-bound so `valu` carries the binding fraction) and, at
@@ -37,7 +38,7 @@ VALU_PER_TEST = 12           # as implemented: 11 fp32 VALU + 1 v_alignbit per t
 
 WORKLOADS = {   # n_gpus -> (width, height, spp)
     1: (1920, 1080, 512),
-    2: (1920, 1080, 1024),
+    2: (2716, 1528, 512),
     4: (3840, 2160, 512),
     8: (3840, 2160, 1024),
 }
