@@ -177,7 +177,7 @@ def main():
         local_px = float(width) * height / world
         # render_kernel per launch: 16 B seed in + 16 B colour sum out per pixel, scene once.  (The blend
         # with the previous framebuffer -- 48 B per pixel -- is finalize_kernel, an HBM-bound ~25 us pass.)
-        alg_bytes = local_px * (16 + 16) + ((n_spheres + 15) // 16 * 16) * 16 + n_spheres * 28
+        alg_bytes = local_px * (16 + 16) + ((n_spheres + 7) // 8 * 8) * 16 + n_spheres * 28
         achieved = alg_bytes / (kernel_ms_max * 1e-3) * 1e-9
         traffic = None
         try:

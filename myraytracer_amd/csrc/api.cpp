@@ -464,7 +464,7 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     HIP_TRY(c, sync_all(c));
     free_world(c);
 
-    const uint32_t n_padded = (uint32_t)((n + mrt::kChunk - 1) / mrt::kChunk * mrt::kChunk);
+    const uint32_t n_padded = (uint32_t)((n + mrt::kGroup - 1) / mrt::kGroup * mrt::kGroup);
     std::vector<mrt::SphereRec> recs(n_padded ? n_padded : 1);
     for (uint32_t i = 0; i < n_padded; i++) {
         if ((int64_t)i < n) {

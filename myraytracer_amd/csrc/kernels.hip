@@ -355,22 +355,29 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                 // loads of group g+1, then run the 8 x 12 VALU ops of group g while they fly.
                 Sph8 ga, gb;
                 smem_load8(ga, sph_quads, 0u);
+                uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
                 for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
                     const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
                     uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
                     uint32_t c = 0;
                     for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
-                        uint32_t bits = 0;
-                        smem_wait_then_load8(ga, gb, sph_quads, i + 8u, bits);  test8(ga, o, d, a, bits);
-                        const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
-                        smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);     test8(gb, o, d, a, bits);
+                        // the sphere count is padded to 8, not 16: the very last chunk may hold one group only
+                        const bool full = i + 8u < n_padded;
+                        smem_wait_then_load8(ga, gb, sph_quads, full ? i + 8u : 0u, bits);  test8(ga, o, d, a, bits);
+                        uint32_t m;
+                        if (full) {
+                            const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
+                            smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);  test8(gb, o, d, a, bits);
+                            m = ~bits & 0xFFFFu;          // 16 signs, sphere i at bit 15; candidate = discriminant >= 0
+                        } else {
+                            m = (~bits & 0xFFu) << 8;     // 8 signs, same alignment
+                        }
                         MRT_STAMP(1);
-                        // 16 signs in bits[15:0], sphere i at bit 15; candidate = discriminant >= 0
-                        const uint32_t m = weird ? 0u : (~bits & 0xFFFFu);
                         masks[c * 64u] = (uint16_t)m;
-                        nz |= (m != 0u ? 1u : 0u) << c;
+                        nz |= (m < 1u ? m : 1u) << c;
                         MRT_STAMP(2);
                     }
+                    if (weird) nz = 0;                    // such lanes take the literal loop below instead
                     // exact pass over this block's candidates, each lane in increasing sphere index:
                     // every trip handles one candidate of every lane that still has one
                     uint32_t m = 0, base = 0;
@@ -387,9 +394,9 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                         exact_test(spheres[idx], idx, o, d, a, t_sup, best);
                     }
                 }
-                // the last prefetch is never consumed, but its destination SGPRs must stay reserved
-                // until it has landed
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi));
+                // the last prefetches are never consumed, but their destination SGPRs must stay
+                // reserved until they have landed
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi), "+s"(gb.lo), "+s"(gb.hi));
                 if (weird) {
                     for (uint32_t idx = 0; idx < P.n_spheres; idx++)
                         exact_test(spheres[idx], idx, o, d, a, t_sup, best);

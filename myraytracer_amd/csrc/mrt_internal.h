@@ -9,11 +9,12 @@ namespace mrt {
 constexpr uint32_t kBandRows = 8;        // shard granule: 8 image rows (one row of 8x8 wave tiles)
 constexpr uint32_t kTileW = 8;           // one 64-lane wave (= one workgroup) covers an 8x8 pixel tile
 constexpr uint32_t kChunk = 16;          // spheres per chunk of the discriminant sweep (one u16 sign mask)
+constexpr uint32_t kGroup = 8;           // spheres per scalar-load group; the sphere count is padded to this
 constexpr uint32_t kMaxSpheres = 1u << 20;
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
 // the host from the reference's SoA arrays (centres: vec4_f32_data, radii: f32_data;
-// lib.rs:722-799) and padded to a multiple of kChunk with never-hit entries (w = +inf).
+// lib.rs:722-799) and padded to a multiple of kGroup with never-hit entries (w = +inf).
 struct alignas(16) SphereRec { float cx, cy, cz, neg_r2; };
 
 // Everything one raytrace pass needs, passed by value as kernel arguments (-> SGPRs).
@@ -24,7 +25,7 @@ struct KParams {
     mrt_world world;            // shader.wgsl:178-182 (+ dielectric range)
     mrt_camera_raw cam;
     uint32_t n_spheres;         // world.spheres.length
-    uint32_t n_padded;          // multiple of kChunk
+    uint32_t n_padded;          // multiple of kGroup
     uint32_t shard_rank, shard_world;
     const SphereRec* spheres;   // n_padded records
     const float* vec4_data;     // r_vec4_f32_data (shader.wgsl:189-190), 4 floats per texel
