@@ -355,6 +355,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                 // loads of group g+1, then run the 8 x 12 VALU ops of group g while they fly.
                 Sph8 ga, gb;
                 smem_load8(ga, sph_quads, 0u);
+                asm volatile("" : "=s"(gb.lo), "=s"(gb.hi));   // defined (uniform) on every path to the final wait
                 uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
                 for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
                     const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
@@ -364,14 +365,11 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                         // the sphere count is padded to 8, not 16: the very last chunk may hold one group only
                         const bool full = i + 8u < n_padded;
                         smem_wait_then_load8(ga, gb, sph_quads, full ? i + 8u : 0u, bits);  test8(ga, o, d, a, bits);
-                        uint32_t m;
-                        if (full) {
-                            const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
-                            smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);  test8(gb, o, d, a, bits);
-                            m = ~bits & 0xFFFFu;          // 16 signs, sphere i at bit 15; candidate = discriminant >= 0
-                        } else {
-                            m = (~bits & 0xFFu) << 8;     // 8 signs, same alignment
-                        }
+                        const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
+                        smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);
+                        if (full) test8(gb, o, d, a, bits);
+                        // 16 (or 8) signs, sphere i at bit 15; candidate = discriminant >= 0
+                        const uint32_t m = full ? (~bits & 0xFFFFu) : ((~bits & 0xFFu) << 8);
                         MRT_STAMP(1);
                         masks[c * 64u] = (uint16_t)m;
                         nz |= (m < 1u ? m : 1u) << c;
