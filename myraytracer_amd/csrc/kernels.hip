@@ -192,6 +192,16 @@ struct alignas(16) PixAcc { float r, g, b; uint32_t cost; };
 //    coalesced whole-line stores.
 constexpr uint32_t kRingCap = 128;        // < 64 waiting + 64 from a new tile; power of two
 
+// Kernel arguments that are only needed between sweeps (camera, material tables, queue and
+// framebuffer pointers) are re-read from the kernarg segment where they are used: kept in SGPRs
+// across the sweep they would crowd out its 64 sphere-record registers and be spilled to VGPR lanes.
+typedef const KParams __attribute__((address_space(4)))* KArgPtr;
+__device__ __forceinline__ KArgPtr cold_args() {
+    KArgPtr p = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));      // opaque: keeps the loads at their use sites
+    return p;
+}
+
 template <bool COUNT, bool PILOT>
 __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     __shared__ uint16_t mask_lds[kBlockChunks * 64];
@@ -303,24 +313,25 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                 float u = rng_f32(rng); float v = rng_f32(rng);            // :71-75, x then y
                 float vx = base_x + u * pixel_side;
                 float vy = base_y + v * pixel_side;
-                if (P.cam.mode == 0) {
+                const KArgPtr C = cold_args();
+                if (C->cam.mode == 0) {
                     o = v3(0.0f, 0.0f, 0.0f);                               // ORIGIN, :361
                     d = normalize3(v3(vx, vy, -1.0f));                      // :381
                 } else {
                     // extension: look-at thin-lens camera over the same (vx, vy)
-                    V3 p = v3((vx * P.cam.su[0] + vy * P.cam.sv[0]) - P.cam.fw[0],
-                              (vx * P.cam.su[1] + vy * P.cam.sv[1]) - P.cam.fw[1],
-                              (vx * P.cam.su[2] + vy * P.cam.sv[2]) - P.cam.fw[2]);
-                    o = v3(P.cam.origin[0], P.cam.origin[1], P.cam.origin[2]);
-                    if (P.cam.defocus) {
+                    V3 p = v3((vx * C->cam.su[0] + vy * C->cam.sv[0]) - C->cam.fw[0],
+                              (vx * C->cam.su[1] + vy * C->cam.sv[1]) - C->cam.fw[1],
+                              (vx * C->cam.su[2] + vy * C->cam.sv[2]) - C->cam.fw[2]);
+                    o = v3(C->cam.origin[0], C->cam.origin[1], C->cam.origin[2]);
+                    if (C->cam.defocus) {
                         float lx, ly;
                         do {                                                // unit disk by rejection
                             float qx = rng_f32(rng); float qy = rng_f32(rng);
                             lx = 2.0f * qx - 1.0f; ly = 2.0f * qy - 1.0f;
                         } while (__builtin_fmaf(ly, ly, lx * lx) > 1.0f);
-                        V3 off = v3(lx * P.cam.ru[0] + ly * P.cam.rv[0],
-                                    lx * P.cam.ru[1] + ly * P.cam.rv[1],
-                                    lx * P.cam.ru[2] + ly * P.cam.rv[2]);
+                        V3 off = v3(lx * C->cam.ru[0] + ly * C->cam.rv[0],
+                                    lx * C->cam.ru[1] + ly * C->cam.rv[1],
+                                    lx * C->cam.ru[2] + ly * C->cam.rv[2]);
                         o = o + off;
                         d = normalize3(p - off);
                     } else {
@@ -328,7 +339,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                     }
                 }
                 att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
-                depth_left = P.locals.ray_depth;
+                depth_left = C->locals.ray_depth;
                 started++;
                 need_sample = false;
             }
@@ -408,10 +419,11 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                     path_done = true;
                 } else {
                     // rest of sphere_hit for the winning sphere, shader.wgsl:298-309
-                    const V3 center = load_vec4_xyz(P.vec4_data, P.world.spheres.center_base_idx + best);
-                    const float radius = P.f32_data[P.world.spheres.radius_base_idx + best];
-                    const int32_t m_ty = P.i32_data[P.world.spheres.material_ty_base_idx + best];
-                    const int32_t m_idx = P.i32_data[P.world.spheres.material_idx_base_idx + best];
+                    const KArgPtr C = cold_args();
+                    const V3 center = load_vec4_xyz(C->vec4_data, C->world.spheres.center_base_idx + best);
+                    const float radius = C->f32_data[C->world.spheres.radius_base_idx + best];
+                    const int32_t m_ty = C->i32_data[C->world.spheres.material_ty_base_idx + best];
+                    const int32_t m_idx = C->i32_data[C->world.spheres.material_idx_base_idx + best];
                     const V3 at = o + t_sup * d;                            // ray_normalized_at :103-105
                     V3 normal = (at - center) / radius;
                     const bool front_face = dot3(normal, d) <= 0.0f;
@@ -421,19 +433,19 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                     V3 albedo = v3(1.0f, 1.0f, 1.0f), ndir = d;
                     bool scattered;
                     if (m_ty == MRT_LAMBERTIAN) {                           // :203-216
-                        albedo = load_vec4_xyz(P.vec4_data, P.world.lambertians.albedo_base_idx + m_idx);
+                        albedo = load_vec4_xyz(C->vec4_data, C->world.lambertians.albedo_base_idx + m_idx);
                         ndir = normal + normalize3(rng_unit_ball(rng));     // unit_sphere :92-94
                         if (dot3(ndir, ndir) == 0.0f) ndir = normal;
                         scattered = true;
                     } else if (m_ty == MRT_METAL) {                         // :228-242
                         const V3 refl = reflect3(d, normal);
-                        const float fuzz = P.f32_data[P.world.metals.fuzz_base_idx + m_idx];
+                        const float fuzz = C->f32_data[C->world.metals.fuzz_base_idx + m_idx];
                         const V3 ball = rng_unit_ball(rng);
                         ndir = v3(refl.x + fuzz * ball.x, refl.y + fuzz * ball.y, refl.z + fuzz * ball.z);
                         scattered = !(dot3(ndir, normal) <= 0.0f);
-                        albedo = load_vec4_xyz(P.vec4_data, P.world.metals.albedo_base_idx + m_idx);
+                        albedo = load_vec4_xyz(C->vec4_data, C->world.metals.albedo_base_idx + m_idx);
                     } else if (m_ty == MRT_DIELECTRIC) {                    // extension, DESIGN.md §3
-                        const float ior = P.f32_data[P.world.dielectrics.ior_base_idx + m_idx];
+                        const float ior = C->f32_data[C->world.dielectrics.ior_base_idx + m_idx];
                         const float ri = front_face ? (1.0f / ior) : ior;
                         float cos_t = dot3(-d, normal);
                         cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;
