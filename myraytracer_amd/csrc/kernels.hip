@@ -209,22 +209,22 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     const uint32_t lane = threadIdx.x;
     uint16_t* const masks = mask_lds + lane;                  // chunk c at masks[c*64]
 
-    const uint32_t W = P.locals.shape[0], H = P.locals.shape[1];
+    const uint32_t H = P.locals.shape[1];
     const uint32_t spp = PILOT ? P.pilot_spp : P.locals.samples_per_frame;
     const uint32_t n_padded = P.n_padded;
     const SphereRec* __restrict__ spheres = P.spheres;
     const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.spheres;
-    PixAcc* __restrict__ st_acc = reinterpret_cast<PixAcc*>(P.pix_acc);
     const float pixel_side = 2.0f / (float)H;                 // fs_main :373
 
     // pixel id q = (tile << 6) | lane-in-tile -> coordinates
-    auto locate = [&](uint32_t q, uint32_t& px, uint32_t& py, uint32_t& texel) -> bool {
+    auto locate = [&](KArgPtr C, uint32_t q, uint32_t& px, uint32_t& py, uint32_t& texel) -> bool {
         const uint32_t tile = q >> 6, l = q & 63u;
-        const uint32_t tile_x = tile % P.tiles_x, band = tile / P.tiles_x;
+        const uint32_t tile_x = tile % C->tiles_x, band = tile / C->tiles_x;
+        const uint32_t Wc = C->locals.shape[0], Hc = C->locals.shape[1];
         px = tile_x * kTileW + (l & 7u);
-        py = (band * P.shard_world + P.shard_rank) * kBandRows + (l >> 3);    // global row, 0 = bottom
-        texel = (band * kBandRows + (l >> 3)) * W + px;                       // row in this shard (< 2^32 texels)
-        return px < W && py < H;
+        py = (band * C->shard_world + C->shard_rank) * kBandRows + (l >> 3);  // global row, 0 = bottom
+        texel = (band * kBandRows + (l >> 3)) * Wc + px;                      // row in this shard (< 2^32 texels)
+        return px < Wc && py < Hc;
     };
 
     uint32_t head = 0, tail = 0, avail = 0;     // wave-uniform FIFO cursors (mod kRingCap) and fill
@@ -250,22 +250,23 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
         const bool release = has_task && task_done;
         if (release) {
             PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
-            st_acc[texel] = sa;
+            reinterpret_cast<PixAcc*>(cold_args()->pix_acc)[texel] = sa;
             has_task = false;
         }
         // ---- refill: lanes would run dry -> take the next (heaviest remaining) tile of the frame
         const unsigned long long need = __ballot(!has_task);
         if (!queue_empty && avail < (uint32_t)__popcll(need)) {
+            const KArgPtr C = cold_args();
             uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(P.tile_queue, 1u);
+            if (lane == 0) t = atomicAdd(C->tile_queue, 1u);
             t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= P.n_tiles) {
+            if (t >= C->n_tiles) {
                 queue_empty = true;
             } else {
-                const uint32_t tile = P.tile_order ? P.tile_order[t] : t;
+                const uint32_t tile = C->tile_order ? C->tile_order[t] : t;
                 uint32_t fx, fy, ft;
                 const uint32_t fq = (tile << 6) | lane;
-                const bool ok = locate(fq, fx, fy, ft);
+                const bool ok = locate(C, fq, fx, fy, ft);
                 const unsigned long long m = __ballot(ok);
                 if (ok) ring[(tail + rank_in(m)) & (kRingCap - 1u)] = fq;
                 const uint32_t nf = (uint32_t)__popcll(m);
@@ -278,15 +279,17 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
             const uint32_t rk = rank_in(need);
             const bool take = !has_task && rk < avail;
             if (take) {
+                const KArgPtr C = cold_args();
                 uint32_t px, py;
-                locate(ring[(head + rk) & (kRingCap - 1u)], px, py, texel);
-                base_x = (((float)px + 0.5f) - 0.5f * (float)W) * pixel_side;      // fs_main :374
-                base_y = (((float)py + 0.5f) - 0.5f * (float)H) * pixel_side;
-                const uint4 sd = reinterpret_cast<const uint4*>(P.seeds)[texel];      // xoshiro128plus_load :44-47
-                rng.s0 = sd.x ^ P.locals.rng_shuffle[0];
-                rng.s1 = sd.y ^ P.locals.rng_shuffle[1];
-                rng.s2 = sd.z ^ P.locals.rng_shuffle[2];
-                rng.s3 = sd.w ^ P.locals.rng_shuffle[3];
+                locate(C, ring[(head + rk) & (kRingCap - 1u)], px, py, texel);
+                const float Wf = (float)C->locals.shape[0], Hf = (float)C->locals.shape[1];
+                base_x = (((float)px + 0.5f) - 0.5f * Wf) * pixel_side;            // fs_main :374
+                base_y = (((float)py + 0.5f) - 0.5f * Hf) * pixel_side;
+                const uint4 sd = reinterpret_cast<const uint4*>(C->seeds)[texel];     // xoshiro128plus_load :44-47
+                rng.s0 = sd.x ^ C->locals.rng_shuffle[0];
+                rng.s1 = sd.y ^ C->locals.rng_shuffle[1];
+                rng.s2 = sd.z ^ C->locals.rng_shuffle[2];
+                rng.s3 = sd.w ^ C->locals.rng_shuffle[3];
                 color = v3(0.0f, 0.0f, 0.0f);                                         // :376
                 s_done = 0;
                 pix_trips = 0;
