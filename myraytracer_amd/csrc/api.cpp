@@ -33,7 +33,6 @@ struct mrt_ctx {
     uint64_t seed = 0;
     mrt_locals locals{};
     uint32_t frames_done = 0;          // State::sample_count (lib.rs:213, 300)
-    bool shuffle_overridden = false;
 
     uint32_t shard_rank = 0, shard_world = 1;
     uint32_t local_bands = 0;
@@ -41,7 +40,6 @@ struct mrt_ctx {
     mrt_world world{};
     bool have_world = false;
     uint32_t n_spheres = 0, n_padded = 0;
-    mrt_camera camera{};
     mrt_camera_raw cam_raw{};
 
     // device memory (all owned)
@@ -183,7 +181,6 @@ void reset_locals(mrt_ctx* c) {
     c->locals.ray_depth = c->args.ray_depth;
     c->locals.framebuffer_weight = 0.0f;
     c->frames_done = 0;
-    c->shuffle_overridden = false;
 }
 
 uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
@@ -369,7 +366,7 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
     mrt_ctx* c = new (std::nothrow) mrt_ctx();
     if (!c) return fail(nullptr, MRT_ERR_INVALID_ARG, "mrt_create: out of host memory");
     c->device = device; c->args = a; c->seed = seed;
-    c->camera.mode = 0; c->cam_raw.mode = 0;
+    c->cam_raw.mode = 0;
     reset_locals(c);
     auto bail = [&](int st) { g_err = c->err; mrt_destroy(c); return st; };
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(MRT_ERR_HIP); }
@@ -509,7 +506,7 @@ int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
     mrt_camera_raw raw;
     int st = mrt_camera_derive(cam, &raw);
     if (st != MRT_OK) return fail(c, st, "mrt_set_camera: degenerate or invalid camera");
-    c->camera = *cam; c->cam_raw = raw;
+    c->cam_raw = raw;
     c->slot[0].cost_valid = c->slot[1].cost_valid = false;
     return MRT_OK;
 }
@@ -630,7 +627,6 @@ int mrt_redraw(mrt_ctx* c) {
     if (c->frames_done != UINT32_MAX) c->frames_done++;                   // saturating_add, lib.rs:300
     c->locals.framebuffer_weight = mrt_frame_weight(c->frames_done, c->args.max_framebuffer_weight);  // :301-304
     mrt_frame_shuffle(c->seed, c->frames_done, c->locals.rng_shuffle);    // :305 (deterministic stand-in)
-    c->shuffle_overridden = false;
     return MRT_OK;
 }
 
@@ -707,7 +703,6 @@ int mrt_get_locals(mrt_ctx* c, mrt_locals* out) {
 int mrt_set_rng_shuffle(mrt_ctx* c, const uint32_t s[4]) {
     if (!c || !s) return MRT_ERR_INVALID_ARG;
     std::memcpy(c->locals.rng_shuffle, s, 16);
-    c->shuffle_overridden = true;
     return MRT_OK;
 }
 

@@ -287,3 +287,12 @@ def test_native_runner_cli(mrt, tmp_path):
     assert np.array_equal(img, ref[..., :3])
     r = subprocess.run([exe, "--bogus", "1"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2
+
+
+def test_zero_samples_per_frame_is_nan_like_the_reference(mrt, oracle):
+    """shader.wgsl:383: color / f32(sample_count) with sample_count == 0 is 0/0; alpha stays 1."""
+    got, c, _ = gpu_render(mrt, mrt.scene_default(), None, 24, 16, 0, 8, 1)
+    ref = oracle_render(oracle, mrt.scene_default(), None, 24, 16, 0, 8, 1)
+    assert np.isnan(got[..., :3]).all() and np.isnan(ref[..., :3]).all()
+    assert (got[..., 3] == 1.0).all() and (ref[..., 3] == 1.0).all()
+    assert c["samples"] == 0 and c["world_hit_calls"] == 0
