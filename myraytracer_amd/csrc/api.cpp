@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -44,6 +45,9 @@ struct mrt_ctx {
 
     // device memory (all owned)
     mrt::SphereRec* d_spheres = nullptr;
+    mrt::SphereRec* d_pairs = nullptr;     // bounding spheres the sweep tests (one or two spheres each)
+    uint32_t* d_pair_members = nullptr;    // 2 x u32 per pair record
+    float pair_factor = 3.0f;              // pair two spheres if their enclosing radius <= factor * (|r1| + |r2|)
     float* d_vec4 = nullptr;
     float* d_f32 = nullptr;
     int32_t* d_i32 = nullptr;
@@ -127,10 +131,12 @@ void free_frame_buffers(mrt_ctx* c) {
 
 void free_world(mrt_ctx* c) {
     if (c->d_spheres) (void)hipFree(c->d_spheres);
+    if (c->d_pairs) (void)hipFree(c->d_pairs);
+    if (c->d_pair_members) (void)hipFree(c->d_pair_members);
     if (c->d_vec4) (void)hipFree(c->d_vec4);
     if (c->d_f32) (void)hipFree(c->d_f32);
     if (c->d_i32) (void)hipFree(c->d_i32);
-    c->d_spheres = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
+    c->d_spheres = nullptr; c->d_pairs = nullptr; c->d_pair_members = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
     c->have_world = false;
 }
 
@@ -191,6 +197,81 @@ uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
 }
 
 bool finite_in_range(float v, float lim) { return std::isfinite(v) && std::fabs(v) <= lim; }
+
+// Sweep records.  The kernel's discriminant sweep does not need the spheres themselves, only a
+// conservative "could this ray touch it" test, so spatially close spheres are tested in PAIRS through
+// one bounding sphere (half the sweep) and the exact per-sphere tests run on the members of the few
+// pairs that pass.  Spheres are ordered along a Morton curve and neighbours are paired when the
+// enclosing sphere is not much larger than the two (`factor`); everything else stays single.
+// R is 6 % above the enclosing radius: part of the conservativeness argument in DESIGN.md §4.
+// Output is padded to a multiple of kGroup with never-hit records (-R^2 = +inf).
+void build_pairs(const float* centers4, const float* radii, uint32_t n, float factor,
+                 std::vector<mrt::SphereRec>& pairs, std::vector<uint32_t>& members) {
+    pairs.clear(); members.clear();
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    if (n > 1) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        std::vector<double> rs(n);
+        for (uint32_t i = 0; i < n; i++) rs[i] = std::fabs((double)radii[i]);
+        std::vector<double> sorted = rs;
+        std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+        const double big = 8.0 * sorted[n / 2];              // e.g. a ground sphere: never paired, kept out of the box
+        for (uint32_t i = 0; i < n; i++) {
+            if (rs[i] > big) continue;
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)centers4[4 * i + k]); hi[k] = std::max(hi[k], (double)centers4[4 * i + k]); }
+        }
+        std::vector<uint64_t> codes(n);
+        for (uint32_t i = 0; i < n; i++) {
+            if (rs[i] > big) { codes[i] = ~0ull; continue; }  // large spheres sort to the end
+            uint32_t q[3];
+            for (int k = 0; k < 3; k++) {
+                const double ext = hi[k] - lo[k];
+                double t = ext > 0 ? ((double)centers4[4 * i + k] - lo[k]) / ext : 0.0;
+                t = t < 0 ? 0 : (t > 1 ? 1 : t);
+                q[k] = (uint32_t)(t * 1023.0);
+            }
+            uint64_t code = 0;
+            for (int bit = 9; bit >= 0; bit--)
+                for (int k = 0; k < 3; k++) code = (code << 1) | ((q[k] >> bit) & 1u);
+            codes[i] = code;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] < codes[b]; });
+    }
+    auto emit = [&](double cx, double cy, double cz, double R, uint32_t m0, uint32_t m1) {
+        const float Rf = (float)(R * 1.06) + 1e-30f;
+        pairs.push_back(mrt::SphereRec{(float)cx, (float)cy, (float)cz, -(Rf * Rf)});
+        members.push_back(m0); members.push_back(m1);
+    };
+    for (uint32_t k = 0; k < n;) {
+        const uint32_t i = order[k];
+        const double ri = std::fabs((double)radii[i]);
+        const double ci[3] = {centers4[4 * i], centers4[4 * i + 1], centers4[4 * i + 2]};
+        bool paired = false;
+        if (k + 1 < n) {
+            const uint32_t j = order[k + 1];
+            const double rj = std::fabs((double)radii[j]);
+            const double cj[3] = {centers4[4 * j], centers4[4 * j + 1], centers4[4 * j + 2]};
+            const double dx = cj[0] - ci[0], dy = cj[1] - ci[1], dz = cj[2] - ci[2];
+            const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
+            double R, t;                                      // enclosing sphere: centre = ci + t * (cj - ci)
+            if (dist + rj <= ri) { R = ri; t = 0.0; }         // j inside i
+            else if (dist + ri <= rj) { R = rj; t = 1.0; }    // i inside j
+            else { R = 0.5 * (dist + ri + rj); t = dist > 0 ? (R - ri) / dist : 0.0; }
+            if (R <= (double)factor * (ri + rj)) {
+                // the float-rounded centre moves by < 1e-6 of its magnitude; the 6 % on R absorbs it
+                emit(ci[0] + t * dx, ci[1] + t * dy, ci[2] + t * dz, R, i < j ? i : j, i < j ? j : i);
+                paired = true;
+                k += 2;
+            }
+        }
+        if (!paired) { emit(ci[0], ci[1], ci[2], ri, i, 0xFFFFFFFFu); k += 1; }
+    }
+    while (pairs.empty() || pairs.size() % mrt::kGroup != 0) {
+        pairs.push_back(mrt::SphereRec{0.0f, 0.0f, 0.0f, INFINITY});    // S = -inf: never a candidate
+        members.push_back(0u); members.push_back(0xFFFFFFFFu);
+    }
+}
 
 // wait for everything this context has in flight (caller's stream and both side streams)
 hipError_t sync_all(mrt_ctx* c) {
@@ -461,23 +542,27 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     HIP_TRY(c, sync_all(c));
     free_world(c);
 
-    const uint32_t n_padded = (uint32_t)((n + mrt::kGroup - 1) / mrt::kGroup * mrt::kGroup);
-    std::vector<mrt::SphereRec> recs(n_padded ? n_padded : 1);
-    for (uint32_t i = 0; i < n_padded; i++) {
-        if ((int64_t)i < n) {
-            const float* ctr = vec4 + 4 * (w->spheres.center_base_idx + i);
-            const float r = f32[w->spheres.radius_base_idx + i];
-            recs[i] = mrt::SphereRec{ctr[0], ctr[1], ctr[2], -(r * r)};
-        } else {
-            recs[i] = mrt::SphereRec{0.0f, 0.0f, 0.0f, INFINITY};   // discriminant = -inf: never a candidate
-        }
+    // exact-test records, in the reference's sphere order
+    std::vector<mrt::SphereRec> recs((size_t)n ? (size_t)n : 1);
+    for (int64_t i = 0; i < n; i++) {
+        const float* ctr = vec4 + 4 * (w->spheres.center_base_idx + i);
+        const float r = f32[w->spheres.radius_base_idx + i];
+        recs[(size_t)i] = mrt::SphereRec{ctr[0], ctr[1], ctr[2], -(r * r)};
     }
+    // sweep records: bounding spheres of spatially close pairs
+    std::vector<mrt::SphereRec> pairs;
+    std::vector<uint32_t> members;
+    build_pairs(vec4 + 4 * w->spheres.center_base_idx, f32 + w->spheres.radius_base_idx, (uint32_t)n,
+                c->pair_factor, pairs, members);
+    const uint32_t n_padded = (uint32_t)pairs.size();
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
         if (e != hipSuccess || !bytes) return e;
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     HIP_TRY(c, upload((void**)&c->d_spheres, recs.data(), recs.size() * sizeof(mrt::SphereRec)));
+    HIP_TRY(c, upload((void**)&c->d_pairs, pairs.data(), pairs.size() * sizeof(mrt::SphereRec)));
+    HIP_TRY(c, upload((void**)&c->d_pair_members, members.data(), members.size() * sizeof(uint32_t)));
     HIP_TRY(c, upload((void**)&c->d_vec4, vec4, n_vec4 * 4 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
@@ -572,7 +657,7 @@ int mrt_redraw(mrt_ctx* c) {
     p.n_spheres = c->n_spheres;
     p.n_padded = c->n_padded;
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
-    p.spheres = c->d_spheres; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
+    p.spheres = c->d_spheres; p.pairs = c->d_pairs; p.pair_members = c->d_pair_members; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
     p.seeds = c->d_seeds;
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
     p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)

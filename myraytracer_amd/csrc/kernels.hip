@@ -87,9 +87,14 @@ __device__ __forceinline__ V3 load_vec4_xyz(const float* vec4_data, int32_t idx)
     return v3(v.x, v.y, v.z);
 }
 
-// One exact sphere test for the candidate `idx`: shader.wgsl:274-296 with the hit record
-// deferred (only t and the index are kept; at/normal/material are rebuilt once per bounce
-// from the winning sphere, which gives the same values because they depend only on t).
+// One exact sphere test for the sphere `idx`: shader.wgsl:274-296 with the hit record deferred
+// (only t and the index are kept; at/normal/material are rebuilt once per bounce from the winning
+// sphere, which gives the same values because they depend only on t).
+// Candidates do not arrive in index order (they come pair by pair), so the reference's tie rule --
+// the scan runs in index order and `t_sup <= t` rejects a later sphere at the same t, i.e. the
+// LOWEST index wins -- is applied explicitly: a root is accepted if it is closer than the best so
+// far, or equally close with a lower sphere index.  Either processing order ends at the
+// lexicographic minimum of (t, index) over all spheres with a root in [t_min, 1e4).
 __device__ __forceinline__ void exact_test(const SphereRec s, uint32_t idx, V3 o, V3 d, float a,
                                            float& t_sup, int32_t& best) {
     V3 oc = v3(o.x - s.cx, o.y - s.cy, o.z - s.cz);
@@ -100,11 +105,32 @@ __device__ __forceinline__ void exact_test(const SphereRec s, uint32_t idx, V3 o
         float d_sqrt = __builtin_sqrtf(disc);                    // :286
         const float t_min = 0.001f;                              // :340
         float t = (-b - d_sqrt) / a;                             // :290
-        if (t < t_min || t_sup <= t) t = (-b + d_sqrt) / a;      // :291-293
-        if (!(t < t_min || t_sup <= t)) {                        // :294-296
+        bool ok = !(t < t_min) && (t < t_sup || (t == t_sup && (int32_t)idx < best));
+        if (!ok) {                                               // :291-293
+            t = (-b + d_sqrt) / a;
+            ok = !(t < t_min) && (t < t_sup || (t == t_sup && (int32_t)idx < best));
+        }
+        if (ok) {                                                // :294-296
             t_sup = t;                                           // world_hit :322
             best = (int32_t)idx;
         }
+    }
+}
+
+// The reference's literal acceptance test, for the index-ordered loop over ALL spheres that rays
+// with a non-finite or non-unit direction take: NaN compares false, so a NaN root is accepted.
+__device__ __forceinline__ void literal_test(const SphereRec s, uint32_t idx, V3 o, V3 d, float a,
+                                             float& t_sup, int32_t& best) {
+    V3 oc = v3(o.x - s.cx, o.y - s.cy, o.z - s.cz);
+    float b = dot3(oc, d);
+    float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, s.neg_r2)));
+    float disc = __builtin_fmaf(b, b, -(a * c));
+    if (!(disc < 0.0f)) {
+        float d_sqrt = __builtin_sqrtf(disc);
+        const float t_min = 0.001f;
+        float t = (-b - d_sqrt) / a;
+        if (t < t_min || t_sup <= t) t = (-b + d_sqrt) / a;
+        if (!(t < t_min || t_sup <= t)) { t_sup = t; best = (int32_t)idx; }
     }
 }
 
@@ -133,23 +159,28 @@ __device__ __forceinline__ void smem_wait_then_load8(Sph8& cur, Sph8& nxt, SphQu
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %2, %5, 0x0\n\ts_load_dwordx16 %3, %5, 0x40"
                  : "+s"(cur.lo), "+s"(cur.hi), "=&s"(nxt.lo), "=&s"(nxt.hi), "+v"(bits) : "s"(p));
 }
-// sphere_hit up to the discriminant, shader.wgsl:274-282; sign(disc) is shifted into `bits`
-__device__ __forceinline__ void test1(float cx, float cy, float cz, float neg_r2, V3 o, V3 d, float a, uint32_t& bits) {
-    const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;                                             // :274
-    const float b = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));                          // :278
-    const float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, neg_r2)));  // :279
-    const float disc = __builtin_fmaf(b, b, -(a * c));                                                      // :280
-    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(disc), 31);    // oldest sphere ends in the top bit
+// The sweep's CONSERVATIVE line-vs-bounding-sphere test (10 fp32 VALU + 1 v_alignbit): with `ds` the
+// ray direction stretched by (1 + 3e-5), S = (oc.ds)^2 - (oc.oc - R^2) is >= 0 whenever the
+// reference's discriminant b*b - a*c (shader.wgsl:277-282) of ANY sphere inside the bound is >= 0 --
+// the stretch adds 6e-5*|oc|^2 of slack, two orders above the rounding error of either expression,
+// and R is 6 % larger than the enclosing radius.  False positives only cost an exact
+// test; a false negative cannot happen.  sign(S) is shifted into `bits`.
+__device__ __forceinline__ void test1(float cx, float cy, float cz, float neg_R2, V3 o, V3 ds, uint32_t& bits) {
+    const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+    const float b = __builtin_fmaf(ocz, ds.z, __builtin_fmaf(ocy, ds.y, ocx * ds.x));
+    const float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, neg_R2)));
+    const float S = __builtin_fmaf(b, b, -c);
+    bits = __builtin_amdgcn_alignbit(bits, __float_as_uint(S), 31);       // oldest record ends in the top bit
 }
-__device__ __forceinline__ void test4(const f32x16 q, V3 o, V3 d, float a, uint32_t& bits) {
-    test1(q[0], q[1], q[2], q[3], o, d, a, bits);
-    test1(q[4], q[5], q[6], q[7], o, d, a, bits);
-    test1(q[8], q[9], q[10], q[11], o, d, a, bits);
-    test1(q[12], q[13], q[14], q[15], o, d, a, bits);
+__device__ __forceinline__ void test4(const f32x16 q, V3 o, V3 ds, uint32_t& bits) {
+    test1(q[0], q[1], q[2], q[3], o, ds, bits);
+    test1(q[4], q[5], q[6], q[7], o, ds, bits);
+    test1(q[8], q[9], q[10], q[11], o, ds, bits);
+    test1(q[12], q[13], q[14], q[15], o, ds, bits);
 }
-__device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 d, float a, uint32_t& bits) {
-    test4(g.lo, o, d, a, bits);
-    test4(g.hi, o, d, a, bits);
+__device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits) {
+    test4(g.lo, o, ds, bits);
+    test4(g.hi, o, ds, bits);
 }
 
 // Candidate masks: per wave kBlockChunks x 64 lanes of u16 (one 16-sphere sign mask per chunk
@@ -213,7 +244,8 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     const uint32_t spp = PILOT ? P.pilot_spp : P.locals.samples_per_frame;
     const uint32_t n_padded = P.n_padded;
     const SphereRec* __restrict__ spheres = P.spheres;
-    const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.spheres;
+    const uint32_t* __restrict__ pair_members = P.pair_members;
+    const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.pairs;
     const float pixel_side = 2.0f / (float)H;                 // fs_main :373
 
     // pixel id q = (tile << 6) | lane-in-tile -> coordinates
@@ -361,8 +393,12 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                 int32_t best = -1;
                 // A ray with a non-finite component makes every discriminant NaN, which the
                 // reference treats as "not < 0".  Such lanes take the literal loop below.
+                // So does a direction that is not (nearly) unit length -- normalize() of an overflowed or
+                // zero vector -- for which the sweep's conservative test has no proof.
                 const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
-                                     __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff());
+                                     __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff()) ||
+                                   !(a > 0.999f && a < 1.001f);
+                const V3 ds = v3(d.x * 1.00003f, d.y * 1.00003f, d.z * 1.00003f);
                 // Discriminant sweep + exact pass, in blocks of kBlockChunks x kChunk spheres.
                 // Sphere records are wave-uniform: they are fetched with scalar loads, 8 records (two
                 // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
@@ -378,10 +414,10 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                     for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
                         // the sphere count is padded to 8, not 16: the very last chunk may hold one group only
                         const bool full = i + 8u < n_padded;
-                        smem_wait_then_load8(ga, gb, sph_quads, full ? i + 8u : 0u, bits);  test8(ga, o, d, a, bits);
+                        smem_wait_then_load8(ga, gb, sph_quads, full ? i + 8u : 0u, bits);  test8(ga, o, ds, bits);
                         const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
                         smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);
-                        if (full) test8(gb, o, d, a, bits);
+                        if (full) test8(gb, o, ds, bits);
                         // 16 (or 8) signs, sphere i at bit 15; candidate = discriminant >= 0
                         const uint32_t m = full ? (~bits & 0xFFFFu) : ((~bits & 0xFFu) << 8);
                         MRT_STAMP(1);
@@ -400,10 +436,11 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                             m = masks[cc * 64u];
                             base = blk + cc * kChunk;
                         }
-                        const uint32_t j = (uint32_t)__builtin_clz(m) - 16u;   // sphere base + j, lowest index first
+                        const uint32_t j = (uint32_t)__builtin_clz(m) - 16u;
                         m &= ~(0x8000u >> j);
-                        const uint32_t idx = base + j;
-                        exact_test(spheres[idx], idx, o, d, a, t_sup, best);
+                        const uint2 mem = reinterpret_cast<const uint2*>(pair_members)[base + j];
+                        exact_test(spheres[mem.x], mem.x, o, d, a, t_sup, best);
+                        if (mem.y != 0xFFFFFFFFu) exact_test(spheres[mem.y], mem.y, o, d, a, t_sup, best);
                     }
                 }
                 // the last prefetches are never consumed, but their destination SGPRs must stay
@@ -411,7 +448,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi), "+s"(gb.lo), "+s"(gb.hi));
                 if (weird) {
                     for (uint32_t idx = 0; idx < P.n_spheres; idx++)
-                        exact_test(spheres[idx], idx, o, d, a, t_sup, best);
+                        literal_test(spheres[idx], idx, o, d, a, t_sup, best);
                 }
                 MRT_STAMP(3);
 

@@ -25,9 +25,14 @@ struct KParams {
     mrt_world world;            // shader.wgsl:178-182 (+ dielectric range)
     mrt_camera_raw cam;
     uint32_t n_spheres;         // world.spheres.length
-    uint32_t n_padded;          // multiple of kGroup
+    uint32_t n_padded;          // pair records, multiple of kGroup
     uint32_t shard_rank, shard_world;
-    const SphereRec* spheres;   // n_padded records
+    const SphereRec* spheres;   // n_spheres records in the reference's order (exact tests)
+    // The discriminant sweep runs over PAIR records: the bounding sphere of one or two spheres
+    // (cx,cy,cz,-R^2), n_padded of them (multiple of kGroup, padded with never-hit entries);
+    // pair_members[p] = the one or two sphere indices it stands for (second = 0xFFFFFFFF if none).
+    const SphereRec* pairs;
+    const uint32_t* pair_members;
     const float* vec4_data;     // r_vec4_f32_data (shader.wgsl:189-190), 4 floats per texel
     const float* f32_data;      // r_f32_data
     const int32_t* i32_data;    // r_i32_data
