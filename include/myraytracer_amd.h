@@ -211,6 +211,9 @@ int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since c
 int mrt_debug_read_counters(mrt_ctx* ctx, uint64_t out[16]);
 /* Diagnostic: per-pixel cost (bounce-loop trips) of the last frame, local_rows*width u32. */
 int mrt_debug_read_pixel_costs(mrt_ctx* ctx, uint32_t* out, size_t cap);
+/* Diagnostic / tuning: growth factor of the sweep's sphere clusters (0 = one sphere per record),
+ * used by the next mrt_set_world* call. */
+int mrt_debug_set_cluster_factor(mrt_ctx* ctx, float factor);
 /* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */
 int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);
 /* Diagnostic / tuning: pilot samples per pixel, waves per CU (0 = automatic).  Before the first

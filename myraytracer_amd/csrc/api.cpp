@@ -45,9 +45,10 @@ struct mrt_ctx {
 
     // device memory (all owned)
     mrt::SphereRec* d_spheres = nullptr;
-    mrt::SphereRec* d_pairs = nullptr;     // bounding spheres the sweep tests (one or two spheres each)
-    uint32_t* d_pair_members = nullptr;    // 2 x u32 per pair record
-    float pair_factor = 3.0f;              // pair two spheres if their enclosing radius <= factor * (|r1| + |r2|)
+    mrt::SphereRec* d_clusters = nullptr;  // bounding spheres the sweep tests (up to kClusterK spheres each)
+    mrt::SphereRec* d_members = nullptr;   // kClusterK member records per cluster
+    uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
+    float cluster_factor = 5.5f;           // grow a cluster while its enclosing radius <= factor * largest member radius
     float* d_vec4 = nullptr;
     float* d_f32 = nullptr;
     int32_t* d_i32 = nullptr;
@@ -131,12 +132,13 @@ void free_frame_buffers(mrt_ctx* c) {
 
 void free_world(mrt_ctx* c) {
     if (c->d_spheres) (void)hipFree(c->d_spheres);
-    if (c->d_pairs) (void)hipFree(c->d_pairs);
-    if (c->d_pair_members) (void)hipFree(c->d_pair_members);
+    if (c->d_clusters) (void)hipFree(c->d_clusters);
+    if (c->d_members) (void)hipFree(c->d_members);
+    if (c->d_member_index) (void)hipFree(c->d_member_index);
     if (c->d_vec4) (void)hipFree(c->d_vec4);
     if (c->d_f32) (void)hipFree(c->d_f32);
     if (c->d_i32) (void)hipFree(c->d_i32);
-    c->d_spheres = nullptr; c->d_pairs = nullptr; c->d_pair_members = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
+    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_members = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
     c->have_world = false;
 }
 
@@ -199,24 +201,28 @@ uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
 bool finite_in_range(float v, float lim) { return std::isfinite(v) && std::fabs(v) <= lim; }
 
 // Sweep records.  The kernel's discriminant sweep does not need the spheres themselves, only a
-// conservative "could this ray touch it" test, so spatially close spheres are tested in PAIRS through
-// one bounding sphere (half the sweep) and the exact per-sphere tests run on the members of the few
-// pairs that pass.  Spheres are ordered along a Morton curve and neighbours are paired when the
-// enclosing sphere is not much larger than the two (`factor`); everything else stays single.
+// conservative "could this ray touch it" test, so spatially close spheres are tested in CLUSTERS of up
+// to kClusterK through one bounding sphere (a quarter of the sweep) and the per-sphere discriminants
+// are evaluated only for the members of the few clusters that pass.  Spheres are ordered along a
+// Morton curve and consecutive ones are grouped while the enclosing sphere stays within `factor`
+// times the largest member radius; spheres much larger than the median (a ground sphere) stay alone.
 // R is 6 % above the enclosing radius: part of the conservativeness argument in DESIGN.md §4.
-// Output is padded to a multiple of kGroup with never-hit records (-R^2 = +inf).
-void build_pairs(const float* centers4, const float* radii, uint32_t n, float factor,
-                 std::vector<mrt::SphereRec>& pairs, std::vector<uint32_t>& members) {
-    pairs.clear(); members.clear();
+// Clusters are padded to kClusterK members and the list to a multiple of kGroup with never-hit
+// records (-r^2 = +inf gives a discriminant of -inf).
+void build_clusters(const float* centers4, const float* radii, uint32_t n, float factor,
+                    std::vector<mrt::SphereRec>& clusters, std::vector<mrt::SphereRec>& members,
+                    std::vector<uint32_t>& member_index) {
+    clusters.clear(); members.clear(); member_index.clear();
+    const mrt::SphereRec never{0.0f, 0.0f, 0.0f, INFINITY};
     std::vector<uint32_t> order(n);
-    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::vector<double> rs(n);
+    for (uint32_t i = 0; i < n; i++) { order[i] = i; rs[i] = std::fabs((double)radii[i]); }
+    double big = 1e300;
     if (n > 1) {
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        std::vector<double> rs(n);
-        for (uint32_t i = 0; i < n; i++) rs[i] = std::fabs((double)radii[i]);
         std::vector<double> sorted = rs;
         std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
-        const double big = 8.0 * sorted[n / 2];              // e.g. a ground sphere: never paired, kept out of the box
+        big = 8.0 * sorted[n / 2];
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
         for (uint32_t i = 0; i < n; i++) {
             if (rs[i] > big) continue;
             for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)centers4[4 * i + k]); hi[k] = std::max(hi[k], (double)centers4[4 * i + k]); }
@@ -238,38 +244,58 @@ void build_pairs(const float* centers4, const float* radii, uint32_t n, float fa
         }
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] < codes[b]; });
     }
-    auto emit = [&](double cx, double cy, double cz, double R, uint32_t m0, uint32_t m1) {
-        const float Rf = (float)(R * 1.06) + 1e-30f;
-        pairs.push_back(mrt::SphereRec{(float)cx, (float)cy, (float)cz, -(Rf * Rf)});
-        members.push_back(m0); members.push_back(m1);
+    // enclosing sphere of a set: centre of the members' common bounding box, R = max(|c_m - centre| + r_m)
+    auto enclose = [&](const uint32_t* idx, uint32_t cnt, double ctr[3]) -> double {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t m = 0; m < cnt; m++)
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::min(lo[k], (double)centers4[4 * idx[m] + k] - rs[idx[m]]);
+                hi[k] = std::max(hi[k], (double)centers4[4 * idx[m] + k] + rs[idx[m]]);
+            }
+        for (int k = 0; k < 3; k++) ctr[k] = 0.5 * (lo[k] + hi[k]);
+        double R = 0;
+        for (uint32_t m = 0; m < cnt; m++) {
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) { const double d = (double)centers4[4 * idx[m] + k] - ctr[k]; d2 += d * d; }
+            R = std::max(R, std::sqrt(d2) + rs[idx[m]]);
+        }
+        return R;
     };
     for (uint32_t k = 0; k < n;) {
-        const uint32_t i = order[k];
-        const double ri = std::fabs((double)radii[i]);
-        const double ci[3] = {centers4[4 * i], centers4[4 * i + 1], centers4[4 * i + 2]};
-        bool paired = false;
-        if (k + 1 < n) {
-            const uint32_t j = order[k + 1];
-            const double rj = std::fabs((double)radii[j]);
-            const double cj[3] = {centers4[4 * j], centers4[4 * j + 1], centers4[4 * j + 2]};
-            const double dx = cj[0] - ci[0], dy = cj[1] - ci[1], dz = cj[2] - ci[2];
-            const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);
-            double R, t;                                      // enclosing sphere: centre = ci + t * (cj - ci)
-            if (dist + rj <= ri) { R = ri; t = 0.0; }         // j inside i
-            else if (dist + ri <= rj) { R = rj; t = 1.0; }    // i inside j
-            else { R = 0.5 * (dist + ri + rj); t = dist > 0 ? (R - ri) / dist : 0.0; }
-            if (R <= (double)factor * (ri + rj)) {
-                // the float-rounded centre moves by < 1e-6 of its magnitude; the 6 % on R absorbs it
-                emit(ci[0] + t * dx, ci[1] + t * dy, ci[2] + t * dz, R, i < j ? i : j, i < j ? j : i);
-                paired = true;
-                k += 2;
+        uint32_t idx[mrt::kClusterK];
+        uint32_t cnt = 1;
+        idx[0] = order[k];
+        double ctr[3];
+        double R = enclose(idx, 1, ctr);
+        double rmax = rs[idx[0]];
+        while (cnt < mrt::kClusterK && k + cnt < n && rs[idx[0]] <= big && rs[order[k + cnt]] <= big) {
+            idx[cnt] = order[k + cnt];
+            double c2[3];
+            const double R2 = enclose(idx, cnt + 1, c2);
+            const double rm2 = std::max(rmax, rs[idx[cnt]]);
+            if (R2 > (double)factor * rm2) break;
+            R = R2; rmax = rm2; cnt++;
+            for (int q = 0; q < 3; q++) ctr[q] = c2[q];
+        }
+        // the float-rounded centre moves by < 1e-6 of its magnitude; the 6 % on R absorbs it
+        const float Rf = (float)(R * 1.06) + 1e-30f;
+        clusters.push_back(mrt::SphereRec{(float)ctr[0], (float)ctr[1], (float)ctr[2], -(Rf * Rf)});
+        std::sort(idx, idx + cnt);
+        for (uint32_t m = 0; m < mrt::kClusterK; m++) {
+            if (m < cnt) {
+                const float r = radii[idx[m]];
+                members.push_back(mrt::SphereRec{centers4[4 * idx[m]], centers4[4 * idx[m] + 1], centers4[4 * idx[m] + 2], -(r * r)});
+                member_index.push_back(idx[m]);
+            } else {
+                members.push_back(never);
+                member_index.push_back(0u);
             }
         }
-        if (!paired) { emit(ci[0], ci[1], ci[2], ri, i, 0xFFFFFFFFu); k += 1; }
+        k += cnt;
     }
-    while (pairs.empty() || pairs.size() % mrt::kGroup != 0) {
-        pairs.push_back(mrt::SphereRec{0.0f, 0.0f, 0.0f, INFINITY});    // S = -inf: never a candidate
-        members.push_back(0u); members.push_back(0xFFFFFFFFu);
+    while (clusters.empty() || clusters.size() % mrt::kGroup != 0) {
+        clusters.push_back(never);                                    // S = -inf: never a candidate
+        for (uint32_t m = 0; m < mrt::kClusterK; m++) { members.push_back(never); member_index.push_back(0u); }
     }
 }
 
@@ -549,20 +575,21 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
         const float r = f32[w->spheres.radius_base_idx + i];
         recs[(size_t)i] = mrt::SphereRec{ctr[0], ctr[1], ctr[2], -(r * r)};
     }
-    // sweep records: bounding spheres of spatially close pairs
-    std::vector<mrt::SphereRec> pairs;
-    std::vector<uint32_t> members;
-    build_pairs(vec4 + 4 * w->spheres.center_base_idx, f32 + w->spheres.radius_base_idx, (uint32_t)n,
-                c->pair_factor, pairs, members);
-    const uint32_t n_padded = (uint32_t)pairs.size();
+    // sweep records: bounding spheres of clusters of spatially close spheres
+    std::vector<mrt::SphereRec> clusters, members;
+    std::vector<uint32_t> member_index;
+    build_clusters(vec4 + 4 * w->spheres.center_base_idx, f32 + w->spheres.radius_base_idx, (uint32_t)n,
+                   c->cluster_factor, clusters, members, member_index);
+    const uint32_t n_padded = (uint32_t)clusters.size();
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
         if (e != hipSuccess || !bytes) return e;
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     HIP_TRY(c, upload((void**)&c->d_spheres, recs.data(), recs.size() * sizeof(mrt::SphereRec)));
-    HIP_TRY(c, upload((void**)&c->d_pairs, pairs.data(), pairs.size() * sizeof(mrt::SphereRec)));
-    HIP_TRY(c, upload((void**)&c->d_pair_members, members.data(), members.size() * sizeof(uint32_t)));
+    HIP_TRY(c, upload((void**)&c->d_clusters, clusters.data(), clusters.size() * sizeof(mrt::SphereRec)));
+    HIP_TRY(c, upload((void**)&c->d_members, members.data(), members.size() * sizeof(mrt::SphereRec)));
+    HIP_TRY(c, upload((void**)&c->d_member_index, member_index.data(), member_index.size() * sizeof(uint32_t)));
     HIP_TRY(c, upload((void**)&c->d_vec4, vec4, n_vec4 * 4 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
@@ -657,7 +684,7 @@ int mrt_redraw(mrt_ctx* c) {
     p.n_spheres = c->n_spheres;
     p.n_padded = c->n_padded;
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
-    p.spheres = c->d_spheres; p.pairs = c->d_pairs; p.pair_members = c->d_pair_members; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
+    p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.members = c->d_members; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
     p.seeds = c->d_seeds;
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
     p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
@@ -734,6 +761,13 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
     HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->slot[(c->frame_seq + 1u) & 1u].d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < n; i++) out[i] = tmp[4 * i + 3];
+    return MRT_OK;
+}
+
+// diagnostic / tuning: cluster growth factor used by the NEXT mrt_set_world* call
+int mrt_debug_set_cluster_factor(mrt_ctx* c, float factor) {
+    if (!c || !(factor >= 0.0f)) return MRT_ERR_INVALID_ARG;
+    c->cluster_factor = factor;
     return MRT_OK;
 }
 

@@ -200,7 +200,8 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 #define MRT_STAMP(k) do { } while (0)
 #endif
 
-constexpr uint32_t kBlockChunks = 32;     // 32 chunks x 16 spheres = 512 spheres between exact passes
+constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 spheres between walks
+constexpr uint32_t kListCap = 16;         // per-lane list of members whose discriminant is >= 0
 
 // lanes below `lane` whose bit is set in the 64-bit ballot `mask`
 __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
@@ -237,6 +238,8 @@ template <bool COUNT, bool PILOT>
 __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     __shared__ uint16_t mask_lds[kBlockChunks * 64];
     __shared__ uint32_t ring[kRingCap];       // FIFO of waiting pixels: tile << 6 | lane-in-tile
+    __shared__ uint16_t list_lds[kListCap * 64];
+    uint16_t* const list = list_lds + threadIdx.x;            // entry k at list[k*64]: member index within the block
     const uint32_t lane = threadIdx.x;
     uint16_t* const masks = mask_lds + lane;                  // chunk c at masks[c*64]
 
@@ -244,8 +247,9 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     const uint32_t spp = PILOT ? P.pilot_spp : P.locals.samples_per_frame;
     const uint32_t n_padded = P.n_padded;
     const SphereRec* __restrict__ spheres = P.spheres;
-    const uint32_t* __restrict__ pair_members = P.pair_members;
-    const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.pairs;
+    const SphereRec* __restrict__ members = P.members;
+    const uint32_t* __restrict__ member_index = P.member_index;
+    const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.clusters;
     const float pixel_side = 2.0f / (float)H;                 // fs_main :373
 
     // pixel id q = (tile << 6) | lane-in-tile -> coordinates
@@ -426,9 +430,11 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                         MRT_STAMP(2);
                     }
                     if (weird) nz = 0;                    // such lanes take the literal loop below instead
-                    // exact pass over this block's candidates, each lane in increasing sphere index:
-                    // every trip handles one candidate of every lane that still has one
-                    uint32_t m = 0, base = 0;
+                    // Walk, phase A: every lane goes through its own candidate clusters and evaluates the
+                    // reference's discriminant (shader.wgsl:274-282) for their members; the few members
+                    // with disc >= 0 go on the lane's short list in LDS.  One cluster of every lane that
+                    // still has one per trip.
+                    uint32_t m = 0, base = 0, lcnt = 0;
                     while ((nz | m) != 0u) {
                         if (m == 0u) {
                             const uint32_t cc = (uint32_t)__builtin_ctz(nz);
@@ -438,9 +444,32 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                         }
                         const uint32_t j = (uint32_t)__builtin_clz(m) - 16u;
                         m &= ~(0x8000u >> j);
-                        const uint2 mem = reinterpret_cast<const uint2*>(pair_members)[base + j];
-                        exact_test(spheres[mem.x], mem.x, o, d, a, t_sup, best);
-                        if (mem.y != 0xFFFFFFFFu) exact_test(spheres[mem.y], mem.y, o, d, a, t_sup, best);
+                        const uint32_t first = (base + j) * kClusterK;
+                        if (lcnt > kListCap - kClusterK) {       // rare: make room (phase B for this lane now)
+                            for (uint32_t k = 0; k < lcnt; k++) {
+                                const uint32_t mi = blk * kClusterK + list[k * 64u];
+                                exact_test(members[mi], member_index[mi], o, d, a, t_sup, best);
+                            }
+                            lcnt = 0;
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < kClusterK; k++) {
+                            const SphereRec s = members[first + k];
+                            const float ocx = o.x - s.cx, ocy = o.y - s.cy, ocz = o.z - s.cz;
+                            const float b = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));
+                            const float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, s.neg_r2)));
+                            const float disc = __builtin_fmaf(b, b, -(a * c));
+                            if (!(disc < 0.0f)) {
+                                list[lcnt * 64u] = (uint16_t)(first + k - blk * kClusterK);
+                                lcnt++;
+                            }
+                        }
+                    }
+                    // Walk, phase B: the reference's sqrt / divide / range tests (shader.wgsl:286-296) for
+                    // the listed members; trips = the largest list in the wave.
+                    for (uint32_t k = 0; k < lcnt; k++) {
+                        const uint32_t mi = blk * kClusterK + list[k * 64u];
+                        exact_test(members[mi], member_index[mi], o, d, a, t_sup, best);
                     }
                 }
                 // the last prefetches are never consumed, but their destination SGPRs must stay

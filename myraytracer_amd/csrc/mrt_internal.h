@@ -9,7 +9,8 @@ namespace mrt {
 constexpr uint32_t kBandRows = 8;        // shard granule: 8 image rows (one row of 8x8 wave tiles)
 constexpr uint32_t kTileW = 8;           // one 64-lane wave (= one workgroup) covers an 8x8 pixel tile
 constexpr uint32_t kChunk = 16;          // spheres per chunk of the discriminant sweep (one u16 sign mask)
-constexpr uint32_t kGroup = 8;           // spheres per scalar-load group; the sphere count is padded to this
+constexpr uint32_t kGroup = 8;           // records per scalar-load group; the sweep list is padded to this
+constexpr uint32_t kClusterK = 4;        // spheres per sweep record (cluster)
 constexpr uint32_t kMaxSpheres = 1u << 20;
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
@@ -25,14 +26,16 @@ struct KParams {
     mrt_world world;            // shader.wgsl:178-182 (+ dielectric range)
     mrt_camera_raw cam;
     uint32_t n_spheres;         // world.spheres.length
-    uint32_t n_padded;          // pair records, multiple of kGroup
+    uint32_t n_padded;          // cluster records, multiple of kGroup
     uint32_t shard_rank, shard_world;
     const SphereRec* spheres;   // n_spheres records in the reference's order (exact tests)
-    // The discriminant sweep runs over PAIR records: the bounding sphere of one or two spheres
-    // (cx,cy,cz,-R^2), n_padded of them (multiple of kGroup, padded with never-hit entries);
-    // pair_members[p] = the one or two sphere indices it stands for (second = 0xFFFFFFFF if none).
-    const SphereRec* pairs;
-    const uint32_t* pair_members;
+    // The discriminant sweep runs over CLUSTER records: the bounding sphere (cx,cy,cz,-R^2) of up to
+    // kClusterK spatially close spheres, n_padded of them (multiple of kGroup, padded with never-hit
+    // entries).  Cluster c stands for members[c*kClusterK .. +kClusterK) (short clusters are padded
+    // with never-hit records); member_index[] is each member's index in the reference's sphere order.
+    const SphereRec* clusters;
+    const SphereRec* members;
+    const uint32_t* member_index;
     const float* vec4_data;     // r_vec4_f32_data (shader.wgsl:189-190), 4 floats per texel
     const float* f32_data;      // r_f32_data
     const int32_t* i32_data;    // r_i32_data

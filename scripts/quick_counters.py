@@ -15,6 +15,9 @@ def run(scene, w, h, spp, depth=50, frames=2, shard=None):
             from myraytracer_amd import _lib
             a_ = [int(x) for x in sched.split(",")]
             assert _lib.load().mrt_debug_set_schedule(st._ctx, a_[0], a_[1]) == 0
+        if os.environ.get("MRT_CLUSTER"):
+            from myraytracer_amd import _lib
+            _lib.load().mrt_debug_set_cluster_factor(st._ctx, float(os.environ["MRT_CLUSTER"]))
         st.set_world(sp)
         if cam is not None: st.set_camera(cam)
         st.render(1); st.sync()

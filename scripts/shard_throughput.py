@@ -7,6 +7,9 @@ w, h, spp, rank, world = (int(x) for x in sys.argv[1:6])
 K = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 sp, cam = M.scene_cover(1, True)
 with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 1 else None) as st:
+    if os.environ.get("MRT_CLUSTER"):
+        from myraytracer_amd import _lib
+        _lib.load().mrt_debug_set_cluster_factor(st._ctx, float(os.environ["MRT_CLUSTER"]))
     st.set_world(sp); st.set_camera(cam); st.render(2); st.sync()
     t0 = time.perf_counter(); st.render(K); st.sync(); dt = time.perf_counter() - t0
     print(f"{w}x{h}x{spp} shard {rank}/{world}: {dt / K * 1e3:.1f} ms/frame, per-GPU {w * h * spp / world * K / dt * 1e-6:.1f} Msamples/s, "
