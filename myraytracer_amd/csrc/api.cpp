@@ -48,7 +48,7 @@ struct mrt_ctx {
     mrt::SphereRec* d_clusters = nullptr;  // bounding spheres the sweep tests (up to kClusterK spheres each)
     mrt::SphereRec* d_members = nullptr;   // kClusterK member records per cluster
     uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
-    float cluster_factor = 5.5f;           // grow a cluster while its enclosing radius <= factor * largest member radius
+    float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
     float* d_vec4 = nullptr;
     float* d_f32 = nullptr;
     int32_t* d_i32 = nullptr;
@@ -252,7 +252,8 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
                 lo[k] = std::min(lo[k], (double)centers4[4 * idx[m] + k] - rs[idx[m]]);
                 hi[k] = std::max(hi[k], (double)centers4[4 * idx[m] + k] + rs[idx[m]]);
             }
-        for (int k = 0; k < 3; k++) ctr[k] = 0.5 * (lo[k] + hi[k]);
+        // the record stores the centre as f32: measure R from the ROUNDED centre so that it stays an enclosure
+        for (int k = 0; k < 3; k++) ctr[k] = (double)(float)(0.5 * (lo[k] + hi[k]));
         double R = 0;
         for (uint32_t m = 0; m < cnt; m++) {
             double d2 = 0;
@@ -277,8 +278,7 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
             R = R2; rmax = rm2; cnt++;
             for (int q = 0; q < 3; q++) ctr[q] = c2[q];
         }
-        // the float-rounded centre moves by < 1e-6 of its magnitude; the 6 % on R absorbs it
-        const float Rf = (float)(R * 1.06) + 1e-30f;
+        const float Rf = (float)(R * 1.06) + 1e-30f;     // rounding R to f32 moves it by 6e-8 R, the 6 % is for the proof
         clusters.push_back(mrt::SphereRec{(float)ctr[0], (float)ctr[1], (float)ctr[2], -(Rf * Rf)});
         std::sort(idx, idx + cnt);
         for (uint32_t m = 0; m < mrt::kClusterK; m++) {

@@ -51,3 +51,39 @@ def test_random_scene(mrt, oracle, case):
     same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
     assert same.all(), mismatch_report(got, ref)
     assert c["samples"] == cnt.samples and c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
+
+
+@pytest.mark.parametrize("dist,radius", [(50.0, 0.01), (900.0, 0.05), (3000.0, 0.5), (9000.0, 30.0)])
+def test_far_small_spheres_grazing_rays(mrt, oracle, dist, radius):
+    """Where the discriminant is dominated by rounding error (|oc|^2 * eps >> r^2) the brute-force scan
+    accepts and rejects spheres erratically; the clustered conservative sweep must still hand exactly the
+    same candidates to the exact tests.  A dense field of tiny, far spheres seen through a narrow lens."""
+    rng = np.random.default_rng(int(dist))
+    n = 200
+    sc = np.zeros(n + 1, mrt.SPHERE_DTYPE)
+    sc[0] = ((0, -1000.0 - dist * 0.02, -dist), 1000.0, 1, (0.5, 0.5, 0.5), 0.0)
+    for i in range(n):
+        c = (rng.uniform(-1, 1) * dist * 0.02, rng.uniform(-1, 1) * dist * 0.012, -dist + rng.uniform(-1, 1) * dist * 0.02)
+        sc[i + 1] = (c, radius * rng.uniform(0.5, 1.5), int(rng.integers(1, 4)), tuple(rng.uniform(0.2, 1, 3)), 0.3 if i % 2 else 1.5)
+    cam = mrt.Camera(1, (0, 0, 0), (0, 0, -1), (0, 1, 0), 3.0, 0.0, 1.0)
+    cnt = oracle.Counters()
+    ref = oracle_render(oracle, sc, cam, 96, 64, 8, 8, 17, counters=cnt)
+    got, c, _ = gpu_render(mrt, sc, cam, 96, 64, 8, 8, 17)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    assert c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
+    assert cnt.scatter_lambertian + cnt.scatter_metal + cnt.scatter_dielectric > 1000     # the spheres are really hit
+
+
+def test_large_coordinates_keep_cluster_bounds_conservative(mrt, oracle):
+    """Cluster centres are stored as f32; at |centre| ~ 1e6 one ulp (0.06) is comparable to the spheres'
+    radii, so the bound must be measured from the rounded centre."""
+    rng = np.random.default_rng(5)
+    n = 64
+    base = np.array([1.0e6, -2.0e5, -1.0e6])
+    sc = np.zeros(n, mrt.SPHERE_DTYPE)
+    for i in range(n):
+        sc[i] = (tuple(base + rng.uniform(-2, 2, 3)), rng.uniform(0.05, 0.4), int(rng.integers(1, 4)), tuple(rng.uniform(0.2, 1, 3)), 0.2 if i % 2 else 1.5)
+    cam = mrt.Camera(1, tuple(base + np.array([0.0, 0.0, 12.0])), tuple(base), (0, 1, 0), 25.0, 0.0, 12.0)
+    ref = oracle_render(oracle, sc, cam, 80, 60, 6, 10, 3)
+    got, _, _ = gpu_render(mrt, sc, cam, 80, 60, 6, 10, 3)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
