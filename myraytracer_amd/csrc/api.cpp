@@ -56,10 +56,11 @@ struct mrt_ctx {
     float* d_fb[2] = {nullptr, nullptr};   // [target, secondary] ping-pong (lib.rs:505-543)
     int target = 0;                        // index of the buffer the NEXT redraw writes
     unsigned long long* d_counters = nullptr;
-    // Two frames may be in flight: frame n's render kernel (sort, pilot) runs on side stream
-    // n % 2 and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
+    // Up to kFrameSlots frames may be in flight: frame n's render kernel (sort, pilot) runs on side
+    // stream n % kFrameSlots and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
     // on the caller's stream.  The next frame's heavy tiles thus start while this frame's last
     // pixels drain (a pixel is one sequential chain, so every frame ends on a thinning chip).
+    static constexpr uint32_t kFrameSlots = 2;      // 3 measured slower: a third persistent grid cannot become resident
     struct FrameSlot {
         hipStream_t stream = nullptr;
         hipEvent_t render_done = nullptr, finalize_done = nullptr;
@@ -68,7 +69,7 @@ struct mrt_ctx {
         uint32_t* d_tile_order = nullptr;
         uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter
         bool cost_valid = false;               // d_tile_cost holds a usable estimate for the current scene
-    } slot[2];
+    } slot[kFrameSlots];
     hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
     bool inputs_dirty = true;
     uint64_t frame_seq = 0;
@@ -593,7 +594,7 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     HIP_TRY(c, upload((void**)&c->d_vec4, vec4, n_vec4 * 4 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
-    c->slot[0].cost_valid = c->slot[1].cost_valid = false;
+    for (auto& S : c->slot) S.cost_valid = false;
     c->inputs_dirty = true;
     c->world = *w;
     c->n_spheres = (uint32_t)n;
@@ -619,7 +620,7 @@ int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
     int st = mrt_camera_derive(cam, &raw);
     if (st != MRT_OK) return fail(c, st, "mrt_set_camera: degenerate or invalid camera");
     c->cam_raw = raw;
-    c->slot[0].cost_valid = c->slot[1].cost_valid = false;
+    for (auto& S : c->slot) S.cost_valid = false;
     return MRT_OK;
 }
 
@@ -692,7 +693,7 @@ int mrt_redraw(mrt_ctx* c) {
     p.wave_log = c->d_wave_log;
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
     p.pilot_spp = c->pilot_spp;
-    mrt_ctx::FrameSlot& S = c->slot[c->frame_seq & 1u];
+    mrt_ctx::FrameSlot& S = c->slot[c->frame_seq % mrt_ctx::kFrameSlots];
     p.tile_queue = S.d_sort_scratch + 1024;
     p.tile_order = nullptr;
     p.tile_cost = S.d_tile_cost;
@@ -758,7 +759,7 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
     HIP_TRY(c, hipSetDevice(c->device));
     std::vector<uint32_t> tmp(n * 4);
     HIP_TRY(c, sync_all(c));
-    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->slot[(c->frame_seq + 1u) & 1u].d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->slot[(c->frame_seq + mrt_ctx::kFrameSlots - 1u) % mrt_ctx::kFrameSlots].d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < n; i++) out[i] = tmp[4 * i + 3];
     return MRT_OK;

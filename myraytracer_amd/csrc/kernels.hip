@@ -161,10 +161,10 @@ __device__ __forceinline__ void smem_wait_then_load8(Sph8& cur, Sph8& nxt, SphQu
 }
 // The sweep's CONSERVATIVE line-vs-bounding-sphere test (10 fp32 VALU + 1 v_alignbit): with `ds` the
 // ray direction stretched by (1 + 3e-5), S = (oc.ds)^2 - (oc.oc - R^2) is >= 0 whenever the
-// reference's discriminant b*b - a*c (shader.wgsl:277-282) of ANY sphere inside the bound is >= 0 --
-// the stretch adds 6e-5*|oc|^2 of slack, two orders above the rounding error of either expression,
-// and R is 6 % larger than the enclosing radius.  False positives only cost an exact
-// test; a false negative cannot happen.  sign(S) is shifted into `bits`.
+// reference's discriminant b*b - a*c (shader.wgsl:277-282) of ANY sphere inside the bound is >= 0:
+// the stretch adds >= 5e-5*|oc|^2 of slack against <= 3.2e-5*|oc|^2 of accumulated rounding error
+// and R is 6 % larger than the enclosing radius (proof sketch: DESIGN.md §4).  False positives only
+// cost a discriminant evaluation; a false negative cannot happen.  sign(S) is shifted into `bits`.
 __device__ __forceinline__ void test1(float cx, float cy, float cz, float neg_R2, V3 o, V3 ds, uint32_t& bits) {
     const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
     const float b = __builtin_fmaf(ocz, ds.z, __builtin_fmaf(ocy, ds.y, ocx * ds.x));
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                 // zero vector -- for which the sweep's conservative test has no proof.
                 const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
                                      __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff()) ||
-                                   !(a > 0.999f && a < 1.001f);
+                                   !(a > 0.99999f && a < 1.00001f);
                 const V3 ds = v3(d.x * 1.00003f, d.y * 1.00003f, d.z * 1.00003f);
                 // Discriminant sweep + exact pass, in blocks of kBlockChunks x kChunk spheres.
                 // Sphere records are wave-uniform: they are fetched with scalar loads, 8 records (two
