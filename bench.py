@@ -34,7 +34,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz: fp32 VALU lane-ops/s
 FLOP_PER_TEST = 23           # algorithmic flop per ray-sphere test (unfused count)
-VALU_PER_TEST = 12           # as implemented: 11 fp32 VALU + 1 v_alignbit per test
+VALU_PER_BOUND_TEST = 11     # as implemented: 10 fp32 VALU + 1 v_alignbit per cluster-bound test
+VALU_PER_MEMBER_TEST = 13    # 11 fp32 VALU + compare + list bookkeeping per member discriminant
 
 WORKLOADS = {   # n_gpus -> (width, height, spp)
     1: (1920, 1080, 512),
@@ -161,12 +162,13 @@ def main():
     # whole-job numbers: max time over ranks, summed counters
     stats = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=device)
     sums = torch.tensor([c1["world_hit_calls"] - c0["world_hit_calls"], c1["samples"] - c0["samples"],
-                         c1["lane_slots"] - c0["lane_slots"]], dtype=torch.float64, device=device)
+                         c1["lane_slots"] - c0["lane_slots"], c1["member_tests"] - c0["member_tests"]],
+                        dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     elapsed_max, kernel_ms_max = float(stats[0]), float(stats[1])
-    hits, samples_counted, lane_slots = float(sums[0]), float(sums[1]), float(sums[2])
+    hits, samples_counted, lane_slots, member_tests = (float(x) for x in sums)
 
     if rank == 0:
         total_samples = float(width) * height * spp * a.steps
@@ -205,13 +207,19 @@ def main():
                          "note": "kernel_ms = mean launch duration (HIP events on its stream); launches of consecutive "
                                  "frames overlap, so it is longer than ms_per_step",
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "valu": {"note": "the binding resource: fp32 VALU issue of the ray-sphere discriminant sweep",
-                     "sphere_tests_per_launch": tests_per_launch,
+            "valu": {"note": "the binding resource is fp32 VALU issue.  `algorithmic_*` = what the reference's linear scan "
+                             "(one test per sphere per world_hit, 23 flop each) would execute; the kernel sweeps cluster bounds "
+                             "and evaluates member discriminants only for candidate clusters, so the algorithmic rate may exceed "
+                             "the executed one and the fp32 peak; `executed_*` is what the kernel ran",
+                     "algorithmic_sphere_tests_per_launch": tests_per_launch,
+                     "algorithmic_tflops": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12, "peak_tflops": FP32_PEAK_TFLOPS,
                      "mean_bounces_per_sample": hits / total_samples if total_samples else None,
                      "lane_utilisation": hits / lane_slots if lane_slots else None,
-                     "achieved_tflops": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12, "peak_tflops": FP32_PEAK_TFLOPS,
-                     "frac": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12 / FP32_PEAK_TFLOPS,
-                     "issue_frac": tests_per_launch * VALU_PER_TEST / kernel_s / LANE_OPS_PEAK},
+                     "executed_bound_tests_per_launch": hits / a.steps / world * c1["sweep_records"] if a.steps else 0.0,
+                     "executed_member_discriminants_per_launch": member_tests / a.steps / world if a.steps else 0.0,
+                     "executed_valu_issue_frac_of_sweep_and_members":
+                         ((hits * c1["sweep_records"] * VALU_PER_BOUND_TEST + member_tests * VALU_PER_MEMBER_TEST)
+                          / max(1, a.steps) / world / kernel_s / LANE_OPS_PEAK) if a.steps else None},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spheres, cam, width, height, a.depth, seed)

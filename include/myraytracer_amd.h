@@ -119,6 +119,9 @@ typedef struct {
     uint64_t rng_draws;            /* xoshiro128+ outputs consumed */
     uint64_t lane_slots;           /* 64 x trips of each wave's bounce loop: world_hit_calls / lane_slots
                                       = SIMD lane utilisation of the kernel (diagnostic, not in the oracle) */
+    uint64_t member_tests;         /* per-sphere discriminants evaluated for the members of candidate clusters */
+    uint64_t sweep_records;        /* cluster records the sweep tests per world_hit (not accumulated): executed
+                                      bound tests = world_hit_calls * sweep_records */
 } mrt_counters;
 
 typedef struct mrt_ctx mrt_ctx;
@@ -206,7 +209,7 @@ void* mrt_framebuffer_device_ptr(mrt_ctx* ctx);
  * world  > 1: this shard's packed rows, local_rows*width*4 floats. */
 int mrt_read_framebuffer(mrt_ctx* ctx, float* rgba_out, size_t cap_floats);
 int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since create/reset */
-/* Diagnostic: the 16 raw u64 counter slots (0..3 = mrt_counters; 4.. are phase cycle sums
+/* Diagnostic: the 16 raw u64 counter slots  (0..4 = mrt_counters; 6.. are phase cycle sums
  * written only by the -DMRT_STAMPS profiling build). */
 int mrt_debug_read_counters(mrt_ctx* ctx, uint64_t out[16]);
 /* Diagnostic: per-pixel cost (bounce-loop trips) of the last frame, local_rows*width u32. */

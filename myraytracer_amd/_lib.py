@@ -77,7 +77,7 @@ class MrtCameraRaw(C.Structure):
 
 class MrtCounters(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("world_hit_calls", C.c_uint64), ("rng_draws", C.c_uint64),
-                ("lane_slots", C.c_uint64)]
+                ("lane_slots", C.c_uint64), ("member_tests", C.c_uint64), ("sweep_records", C.c_uint64)]
 
 
 _lib = None

@@ -313,7 +313,8 @@ class State:
         c = MrtCounters()
         self._check(self._L.mrt_read_counters(self._ctx, C.byref(c)), "mrt_read_counters")
         return {"samples": int(c.samples), "world_hit_calls": int(c.world_hit_calls), "rng_draws": int(c.rng_draws),
-                "lane_slots": int(c.lane_slots)}
+                "lane_slots": int(c.lane_slots), "member_tests": int(c.member_tests),
+                "sweep_records": int(c.sweep_records)}
 
     def kernel_ms_history(self, n: int = 64) -> list:
         """GPU time (ms, HIP events on the launch stream) of the render kernel of the last <= n redraws."""

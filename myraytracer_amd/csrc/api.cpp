@@ -858,10 +858,12 @@ int mrt_read_framebuffer(mrt_ctx* c, float* out, size_t cap) {
 int mrt_read_counters(mrt_ctx* c, mrt_counters* out) {
     if (!c || !out) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    unsigned long long h[4];
+    unsigned long long h[5];
     HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     out->samples = h[0]; out->world_hit_calls = h[1]; out->rng_draws = h[2]; out->lane_slots = h[3];
+    out->member_tests = h[4];
+    out->sweep_records = c->n_padded;
     return MRT_OK;
 }
 

@@ -7,13 +7,14 @@
 //   * the sample loop and the bounce loop (shader.wgsl:378, :339) are flattened into ONE
 //     per-lane state machine: every trip of the wave's loop is one `world_hit` for every
 //     live lane, whichever sample / bounce that lane is on;
-//   * `world_hit` (shader.wgsl:314-329) is split into a branch-free discriminant sweep
-//     over all spheres -- sphere records are wave-uniform, so they are fetched by scalar
-//     loads into SGPRs (no LDS, no VGPRs, no per-lane bandwidth) and each test costs 11
-//     fp32 VALU ops + 1 v_alignbit that shifts the sign of the discriminant into a
-//     per-lane 16-sphere bitmask -- and an exact pass over the few spheres whose
-//     discriminant was non-negative, in index order, with the reference's sqrt / divide /
-//     range tests (shader.wgsl:286-296).  The masks wait in LDS;
+//   * `world_hit` (shader.wgsl:314-329) is split into (1) a branch-free, conservative sweep over
+//     the bounding spheres of clusters of <= 4 neighbouring spheres -- the records are
+//     wave-uniform, so they are fetched by scalar loads into SGPRs (no LDS, no VGPRs, no per-lane
+//     bandwidth); each costs 10 fp32 VALU ops + 1 v_alignbit that shifts the sign of the test
+//     into a per-lane 16-record bitmask kept in LDS -- and (2) a per-lane walk over the lane's
+//     candidate clusters that evaluates the reference's discriminant for their members and then
+//     its sqrt / divide / range tests (shader.wgsl:286-296) for the few with disc >= 0, accepting
+//     lexicographically by (t, sphere index), which is what the reference's index-order scan yields;
 //   * persistent waves pull 8x8 tiles from one global heaviest-first queue and a lane that
 //     finishes its pixel takes the next waiting one (render_kernel);
 //   * finalize_kernel turns the per-pixel colour sums into the framebuffer: one coalesced
@@ -273,7 +274,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     Rng rng; rng.draws = 0; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     V3 color = v3(0.0f, 0.0f, 0.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, -1.0f), att = v3(1.0f, 1.0f, 1.0f);
-    uint32_t depth_left = 0, started = 0, bounces = 0, trips = 0;
+    uint32_t depth_left = 0, started = 0, bounces = 0, trips = 0, mtests = 0;
 
 #ifdef MRT_STAMPS
     uint64_t phase_[6] = {0, 0, 0, 0, 0, 0};
@@ -445,6 +446,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                         const uint32_t j = (uint32_t)__builtin_clz(m) - 16u;
                         m &= ~(0x8000u >> j);
                         const uint32_t first = (base + j) * kClusterK;
+                        if (COUNT) mtests += kClusterK;
                         if (lcnt > kListCap - kClusterK) {       // rare: make room (phase B for this lane now)
                             for (uint32_t k = 0; k < lcnt; k++) {
                                 const uint32_t mi = blk * kClusterK + list[k * 64u];
@@ -561,20 +563,22 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     }
 
     if (COUNT && !PILOT) {
-        unsigned long long c0 = started, c1 = bounces, c2 = rng.draws;
+        unsigned long long c0 = started, c1 = bounces, c2 = rng.draws, c4 = mtests;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             c0 += __shfl_xor(c0, off);
             c1 += __shfl_xor(c1, off);
             c2 += __shfl_xor(c2, off);
+            c4 += __shfl_xor(c4, off);
         }
         if (lane == 0 && P.counters) {
             atomicAdd(P.counters + 0, c0);
             atomicAdd(P.counters + 1, c1);
             atomicAdd(P.counters + 2, c2);
             atomicAdd(P.counters + 3, 64ull * trips);
+            atomicAdd(P.counters + 4, c4);
 #ifdef MRT_STAMPS
-            for (int k = 0; k < 6; k++) atomicAdd(P.counters + 4 + k, (unsigned long long)phase_[k]);
+            for (int k = 0; k < 6; k++) atomicAdd(P.counters + 6 + k, (unsigned long long)phase_[k]);
             if (P.wave_log) {
                 unsigned long long* wl = P.wave_log + 4ull * blockIdx.x;
                 wl[0] = wave_t0_; wl[1] = __builtin_amdgcn_s_memrealtime(); wl[2] = trips; wl[3] = c1;

@@ -16,7 +16,7 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     raw = (C.c_uint64 * 16)()
     _lib.load().mrt_debug_read_counters(st._ctx, raw)
     names = ["new_sample", "sweep", "push", "exact", "shade", "tail"]
-    ph = [raw[4 + k] for k in range(6)]
+    ph = [raw[6 + k] for k in range(6)]
     tot = sum(ph)
     print("kernel ms", st.last_kernel_ms(), "wave sweeps", raw[3] / 64)
     for n, v in zip(names, ph):

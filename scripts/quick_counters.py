@@ -25,7 +25,7 @@ def run(scene, w, h, spp, depth=50, frames=2, shard=None):
         st.render(frames - 1); st.sync()
         c1 = st.read_counters()
         ms = st.kernel_ms_history(frames)[1:]
-        d = {k: (c1[k] - c0[k]) / (frames - 1) for k in c0}
+        d = {k: (c1[k] - c0[k]) / (frames - 1) for k in c0 if k != "sweep_records"}
         n = len(sp)
         ms_avg = sum(ms) / len(ms)
         tests = d["world_hit_calls"] * n
@@ -35,7 +35,8 @@ def run(scene, w, h, spp, depth=50, frames=2, shard=None):
                           "bounces/sample": round(d["world_hit_calls"] / d["samples"], 3),
                           "lane_util": round(d["world_hit_calls"] / max(1, d["lane_slots"]), 4),
                           "Gtests/s": round(tests / ms_avg * 1e-6, 1),
-                          "wave_sweeps": d["lane_slots"] / 64}))
+                          "wave_sweeps": d["lane_slots"] / 64, "sweep_records": c1["sweep_records"],
+                          "member_tests/bounce": round(d["member_tests"] / d["world_hit_calls"], 2)}))
 
 if __name__ == "__main__":
     a = sys.argv[1:]
