@@ -232,8 +232,8 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
         for (uint32_t i = 0; i < n; i++) {
             if (rs[i] > big) { codes[i] = ~0ull; continue; }  // large spheres sort to the end
             uint32_t q[3];
+            const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));   // one scale for all axes
             for (int k = 0; k < 3; k++) {
-                const double ext = hi[k] - lo[k];
                 double t = ext > 0 ? ((double)centers4[4 * i + k] - lo[k]) / ext : 0.0;
                 t = t < 0 ? 0 : (t > 1 ? 1 : t);
                 q[k] = (uint32_t)(t * 1023.0);
