@@ -69,8 +69,15 @@ typedef struct {
     uint32_t ray_depth;
     uint32_t rng_shuffle[4];
     float    framebuffer_weight;
-    uint32_t _padding[3];
+    uint32_t rng_mode;          /* the reference's first padding word: 0 = its per-pixel stream (MRT_RNG_*) */
+    uint32_t _padding[2];
 } mrt_locals;
+
+/* RNG modes.  0 is the reference: one sequential Xoshiro128+ stream per pixel per frame
+ * (shader.wgsl:377-382).  1 is an extension (north_star's "counter-based RNG per lane"): every sample
+ * starts from a hash of (seed texel ^ rng_shuffle, sample index), so samples are independent of how
+ * many draws earlier samples consumed; within a sample the draw order is the reference's. */
+enum { MRT_RNG_PIXEL_STREAM = 0, MRT_RNG_COUNTER = 1 };
 
 /* ---- raw::World, lib.rs:641-685 / shader.wgsl:109-124,165-182 (64 bytes) plus the
  *      Dielectric extension appended after MetalRange (80 bytes total) ---- */
@@ -188,6 +195,7 @@ int mrt_get_locals(mrt_ctx* ctx, mrt_locals* out);
 /* Override the next frame's rng_shuffle (the reference draws it from thread_rng, lib.rs:305) */
 int mrt_set_rng_shuffle(mrt_ctx* ctx, const uint32_t shuffle[4]);
 int mrt_set_samples_per_frame(mrt_ctx* ctx, uint32_t spp);
+int mrt_set_rng_mode(mrt_ctx* ctx, uint32_t mode);          /* MRT_RNG_*; takes effect at the next redraw */
 uint32_t mrt_frames_done(mrt_ctx* ctx);
 
 /* host-only helpers exposing the schedule of lib.rs:300-305 */

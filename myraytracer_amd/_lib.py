@@ -16,7 +16,7 @@ EXPORTS = [
     "mrt_args_default", "mrt_args_resolve_size", "mrt_create", "mrt_destroy", "mrt_set_shard",
     "mrt_set_stream", "mrt_set_world_raw", "mrt_set_world", "mrt_pack_world", "mrt_set_camera",
     "mrt_camera_derive", "mrt_set_seeds", "mrt_read_seeds", "mrt_redraw", "mrt_render", "mrt_sync",
-    "mrt_reset", "mrt_get_locals", "mrt_set_rng_shuffle", "mrt_set_samples_per_frame",
+    "mrt_reset", "mrt_get_locals", "mrt_set_rng_shuffle", "mrt_set_samples_per_frame", "mrt_set_rng_mode",
     "mrt_frames_done", "mrt_frame_weight", "mrt_frame_shuffle", "mrt_pixel_seed", "mrt_shard_info",
     "mrt_framebuffer_device_ptr", "mrt_read_framebuffer", "mrt_read_counters", "mrt_last_kernel_ms",
     "mrt_kernel_ms_history", "mrt_debug_read_counters", "mrt_debug_wave_log", "mrt_debug_set_tile_sort", "mrt_debug_set_cluster_factor", "mrt_debug_read_pixel_costs", "mrt_debug_set_schedule",
@@ -32,7 +32,8 @@ class MrtArgs(C.Structure):
 
 class MrtLocals(C.Structure):
     _fields_ = [("shape", C.c_uint32 * 2), ("samples_per_frame", C.c_uint32), ("ray_depth", C.c_uint32),
-                ("rng_shuffle", C.c_uint32 * 4), ("framebuffer_weight", C.c_float), ("_padding", C.c_uint32 * 3)]
+                ("rng_shuffle", C.c_uint32 * 4), ("framebuffer_weight", C.c_float), ("rng_mode", C.c_uint32),
+                ("_padding", C.c_uint32 * 2)]
 
 
 class MrtSphereRange(C.Structure):
@@ -117,6 +118,7 @@ def load():
         "mrt_get_locals": (i32, [vp, P(MrtLocals)]),
         "mrt_set_rng_shuffle": (i32, [vp, P(u32)]),
         "mrt_set_samples_per_frame": (i32, [vp, u32]),
+        "mrt_set_rng_mode": (i32, [vp, u32]),
         "mrt_frames_done": (u32, [vp]),
         "mrt_frame_weight": (f32, [u32, f32]),
         "mrt_frame_shuffle": (None, [u64, u32, P(u32)]),

@@ -284,6 +284,10 @@ class State:
     def set_rng_shuffle(self, shuffle: Sequence[int]):
         self._check(self._L.mrt_set_rng_shuffle(self._ctx, (C.c_uint32 * 4)(*shuffle)), "mrt_set_rng_shuffle")
 
+    def set_rng_mode(self, mode: int):
+        """0 = the reference's per-pixel stream, 1 = per-sample counter-based states (extension)."""
+        self._check(self._L.mrt_set_rng_mode(self._ctx, mode), "mrt_set_rng_mode")
+
     def set_samples_per_frame(self, spp: int):
         self._check(self._L.mrt_set_samples_per_frame(self._ctx, spp), "mrt_set_samples_per_frame")
 

@@ -807,9 +807,10 @@ int mrt_reset(mrt_ctx* c) {
     HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
-    const uint32_t spp = c->locals.samples_per_frame;
+    const uint32_t spp = c->locals.samples_per_frame, mode = c->locals.rng_mode;
     reset_locals(c);
     c->locals.samples_per_frame = spp;
+    c->locals.rng_mode = mode;
     c->target = 0;
     return MRT_OK;
 }
@@ -823,6 +824,12 @@ int mrt_get_locals(mrt_ctx* c, mrt_locals* out) {
 int mrt_set_rng_shuffle(mrt_ctx* c, const uint32_t s[4]) {
     if (!c || !s) return MRT_ERR_INVALID_ARG;
     std::memcpy(c->locals.rng_shuffle, s, 16);
+    return MRT_OK;
+}
+
+int mrt_set_rng_mode(mrt_ctx* c, uint32_t mode) {
+    if (!c || mode > MRT_RNG_COUNTER) return MRT_ERR_INVALID_ARG;
+    c->locals.rng_mode = mode;
     return MRT_OK;
 }
 

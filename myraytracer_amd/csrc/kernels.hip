@@ -73,6 +73,10 @@ __device__ __forceinline__ float rng_f32(Rng& r) {               // shader.wgsl:
     r.draws++;
     return (float)rng_next(r) * 0x1p-32f;                        // == f32(i) / 4294967296.0
 }
+__device__ __forceinline__ uint32_t fmix32(uint32_t z) {         // MurmurHash3 finaliser (counter mode)
+    z ^= z >> 16; z *= 0x85EBCA6Bu; z ^= z >> 13; z *= 0xC2B2AE35u; z ^= z >> 16;
+    return z;
+}
 __device__ __forceinline__ V3 rng_unit_ball(Rng& r) {            // shader.wgsl:84-90
     V3 v;
     do {
@@ -235,7 +239,7 @@ __device__ __forceinline__ KArgPtr cold_args() {
     return p;
 }
 
-template <bool COUNT, bool PILOT>
+template <bool COUNT, bool PILOT, bool CTR>
 __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     __shared__ uint16_t mask_lds[kBlockChunks * 64];
     __shared__ uint32_t ring[kRingCap];       // FIFO of waiting pixels: tile << 6 | lane-in-tile
@@ -272,6 +276,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
     uint32_t s_done = 0, pix_trips = 0, texel = 0;
     float base_x = 0.0f, base_y = 0.0f;
     Rng rng; rng.draws = 0; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    uint32_t base0 = 0, base1 = 0, base2 = 0, base3 = 0;     // CTR: the pixel's frame state, hashed per sample
     V3 color = v3(0.0f, 0.0f, 0.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, -1.0f), att = v3(1.0f, 1.0f, 1.0f);
     uint32_t depth_left = 0, started = 0, bounces = 0, trips = 0, mtests = 0;
@@ -327,6 +332,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                 rng.s1 = sd.y ^ C->locals.rng_shuffle[1];
                 rng.s2 = sd.z ^ C->locals.rng_shuffle[2];
                 rng.s3 = sd.w ^ C->locals.rng_shuffle[3];
+                if (CTR) { base0 = rng.s0; base1 = rng.s1; base2 = rng.s2; base3 = rng.s3; }
                 color = v3(0.0f, 0.0f, 0.0f);                                         // :376
                 s_done = 0;
                 pix_trips = 0;
@@ -349,6 +355,16 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
         if (has_task && !task_done) {
             pix_trips++;
             if (need_sample) {
+                if (CTR) {      // extension: this sample's state = hash(pixel frame state, sample index)
+                    const uint32_t k4 = 4u * s_done;
+                    rng.s0 = fmix32(base0 + 0x9E3779B9u * (k4 + 1u));
+                    rng.s1 = fmix32(base1 + 0x9E3779B9u * (k4 + 2u));
+                    rng.s2 = fmix32(base2 + 0x9E3779B9u * (k4 + 3u));
+                    rng.s3 = fmix32(base3 + 0x9E3779B9u * (k4 + 4u));
+                    if ((rng.s0 | rng.s1 | rng.s2 | rng.s3) == 0u) {
+                        rng.s0 = 0x9E3779B9u; rng.s1 = 0x7F4A7C15u; rng.s2 = 0xBF58476Du; rng.s3 = 0x1CE4E5B9u;
+                    }
+                }
                 // one trip of the sample loop head, shader.wgsl:378-381
                 float u = rng_f32(rng); float v = rng_f32(rng);            // :71-75, x then y
                 float vx = base_x + u * pixel_side;
@@ -661,13 +677,17 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
     hipError_t e = hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
     dim3 grid(n_waves < p.n_tiles ? n_waves : p.n_tiles), block(64);
+    const bool ctr = p.locals.rng_mode == MRT_RNG_COUNTER;
     if (pilot) {
-        hipLaunchKernelGGL((render_kernel<false, true>), grid, block, 0, st, p);
+        if (ctr) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, 0, st, p);
         hipLaunchKernelGGL((finalize_kernel<true>), dim3(p.n_tiles), block, 0, st, p);
+    } else if (ctr) {
+        hipLaunchKernelGGL((render_kernel<true, false, true>), grid, block, 0, st, p);
     } else if (p.counters) {
-        hipLaunchKernelGGL((render_kernel<true, false>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, 0, st, p);
     } else {
-        hipLaunchKernelGGL((render_kernel<false, false>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, st, p);
     }
     return (int)hipGetLastError();
 }
@@ -682,7 +702,7 @@ int launch_finalize(const KParams& p, void* stream) {
 // how many waves of the render kernel one CU holds (occupancy API)
 int render_waves_per_cu(int* out) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false>, 64, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false, false>, 64, 0);
     *out = nb;
     return (int)e;
 }

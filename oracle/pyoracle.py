@@ -39,7 +39,7 @@ class World(C.Structure):
 class Locals(C.Structure):
     _fields_ = [("shape", C.c_uint32 * 2), ("samples_per_frame", C.c_uint32),
                 ("ray_depth", C.c_uint32), ("rng_shuffle", C.c_uint32 * 4),
-                ("framebuffer_weight", C.c_float), ("_pad", C.c_uint32 * 3)]
+                ("framebuffer_weight", C.c_float), ("rng_mode", C.c_uint32), ("_pad", C.c_uint32 * 2)]
 
 
 class Camera(C.Structure):
@@ -185,13 +185,14 @@ def lookat_camera(lookfrom, lookat, vup, vfov, defocus_angle, focus_dist):
 
 
 def render_frame(width, height, spp, depth, packed, cam, seeds, shuffle=(0, 0, 0, 0), weight=0.0,
-                 prev=None, rows=None, nthreads=0, counters=None):
+                 prev=None, rows=None, nthreads=0, counters=None, rng_mode=0):
     """One pass of fs_main (shader.wgsl:371-386) over rows [rows[0], rows[1]) -> (H,W,4) f32, row 0 = bottom."""
     L = Locals()
     L.shape[0], L.shape[1] = width, height
     L.samples_per_frame, L.ray_depth = spp, depth
     L.rng_shuffle[:] = list(shuffle)
     L.framebuffer_weight = weight
+    L.rng_mode = rng_mode
     if prev is None:
         prev = np.zeros((height, width, 4), np.float32)
     prev = np.ascontiguousarray(prev, np.float32)
@@ -206,11 +207,11 @@ def render_frame(width, height, spp, depth, packed, cam, seeds, shuffle=(0, 0, 0
     return out
 
 
-def render(width, height, spp, depth, packed, cam, seed, frames=1, max_w=1.0, nthreads=0, counters=None):
+def render(width, height, spp, depth, packed, cam, seed, frames=1, max_w=1.0, nthreads=0, counters=None, rng_mode=0):
     """The progressive loop of State::redraw (lib.rs:241-307): `frames` frames of `spp` samples."""
     seeds = fill_seeds(seed, width, height)
     fb = np.zeros((height, width, 4), np.float32)
     for f in range(frames):
         fb = render_frame(width, height, spp, depth, packed, cam, seeds, frame_shuffle(seed, f),
-                          frame_weight(f, max_w), fb, None, nthreads, counters)
+                          frame_weight(f, max_w), fb, None, nthreads, counters, rng_mode)
     return fb

@@ -115,6 +115,21 @@ void orc_frame_shuffle(uint64_t seed, uint32_t frame, uint32_t out[4]) {
     out[0] = (uint32_t)a; out[1] = (uint32_t)(a >> 32);
     out[2] = (uint32_t)b; out[3] = (uint32_t)(b >> 32);
 }
+/* EXTENSION (north_star's "counter-based RNG per lane"; no reference counterpart): in mode
+ * ORC_RNG_COUNTER every sample starts from a Xoshiro128+ state that is a hash of the pixel's
+ * frame state (seed texel ^ rng_shuffle) and the sample's index, so samples do not depend on how
+ * many draws earlier samples consumed.  Within a sample the draw order is the reference's. */
+static inline uint32_t fmix32(uint32_t z) {
+    z ^= z >> 16; z *= 0x85EBCA6Bu; z ^= z >> 13; z *= 0xC2B2AE35u; z ^= z >> 16;
+    return z;
+}
+void orc_sample_state(const uint32_t base[4], uint32_t sample, uint32_t out[4]) {
+    for (uint32_t j = 0; j < 4; j++) out[j] = fmix32(base[j] + 0x9E3779B9u * (4u * sample + j + 1u));
+    if ((out[0] | out[1] | out[2] | out[3]) == 0u) {
+        out[0] = 0x9E3779B9u; out[1] = 0x7F4A7C15u; out[2] = 0xBF58476Du; out[3] = 0x1CE4E5B9u;
+    }
+}
+
 /* lib.rs:300-304: weight used by the NEXT frame after `frames_done` frames */
 float orc_frame_weight(uint32_t frames_done, float max_w) {
     if (frames_done == 0) return 0.0f;   /* lib.rs:424 initial value */
@@ -356,8 +371,11 @@ static void shade_pixel(const orc_locals* L, const scene_t* s, const orc_camera_
     for (int k = 0; k < 4; k++) rng.s[k] = seeds[4 * p + k] ^ L->rng_shuffle[k];
     rng.draws = 0;
 
+    uint32_t base[4];
+    for (int k = 0; k < 4; k++) base[k] = rng.s[k];
     v3 color = v3_make(0.0f, 0.0f, 0.0f);
     for (uint32_t i = 0; i < L->samples_per_frame; i++) {                          /* :378 */
+        if (L->rng_mode == ORC_RNG_COUNTER) orc_sample_state(base, i, rng.s);      /* extension, see header */
         float u = rand_f32(&rng); float v = rand_f32(&rng);                        /* :71-75 */
         float vx = base_x + u * pixel_side;                                        /* :379-380 */
         float vy = base_y + v * pixel_side;

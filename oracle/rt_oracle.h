@@ -62,8 +62,10 @@ typedef struct {
     uint32_t ray_depth;
     uint32_t rng_shuffle[4];
     float framebuffer_weight;
-    uint32_t _pad[3];
+    uint32_t rng_mode;          /* first padding word of the reference's Locals: 0 = its per-pixel stream */
+    uint32_t _pad[2];
 } orc_locals;
+enum { ORC_RNG_PIXEL_STREAM = 0, ORC_RNG_COUNTER = 1 };
 
 /* user-level camera (extension; mode 0 = the fixed pinhole of shader.wgsl:360-381) */
 typedef struct {
@@ -95,6 +97,7 @@ void     orc_pixel_seed(uint64_t seed, uint64_t pixel_index, uint32_t out[4]);
 void     orc_fill_seeds(uint64_t seed, uint32_t w, uint32_t h, uint32_t* seeds /* w*h*4 */);
 void     orc_frame_shuffle(uint64_t seed, uint32_t frame, uint32_t out[4]);
 float    orc_frame_weight(uint32_t frames_done, float max_w);
+void     orc_sample_state(const uint32_t base[4], uint32_t sample, uint32_t out[4]);
 
 /* ---- unit-testable pieces ---- */
 /* returns 1 on hit; out = {at[3], t, normal[3], front_face, ty, idx} */

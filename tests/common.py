@@ -14,18 +14,20 @@ def to_oracle_camera(O, cam):
     return O.lookat_camera(cam.lookfrom, cam.lookat, cam.vup, cam.vfov_deg, cam.defocus_angle_deg, cam.focus_dist)
 
 
-def oracle_render(O, spheres, cam, width, height, spp, depth, seed, frames=1, max_w=1.0, counters=None):
+def oracle_render(O, spheres, cam, width, height, spp, depth, seed, frames=1, max_w=1.0, counters=None, rng_mode=0):
     packed = O.pack_world(to_oracle_spheres(O, spheres))
     return O.render(width, height, spp, depth, packed, to_oracle_camera(O, cam), seed, frames=frames,
-                    max_w=max_w, counters=counters)
+                    max_w=max_w, counters=counters, rng_mode=rng_mode)
 
 
-def gpu_render(M, spheres, cam, width, height, spp, depth, seed, frames=1, max_w=1.0, shard=None):
+def gpu_render(M, spheres, cam, width, height, spp, depth, seed, frames=1, max_w=1.0, shard=None, rng_mode=0):
     args = M.Args(width, height, spp, depth, max_w)
     with M.State(args, seed=seed, shard=shard) as st:
         st.set_world(spheres)
         if cam is not None:
             st.set_camera(cam)
+        if rng_mode:
+            st.set_rng_mode(rng_mode)
         st.render(frames)
         st.sync()
         return st.read_framebuffer(), st.read_counters(), st.last_kernel_ms()

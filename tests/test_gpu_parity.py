@@ -72,3 +72,22 @@ def test_lookat_camera_reduces_to_pinhole(mrt, oracle):
     a, _, _ = gpu_render(mrt, sc, cam, 64, 36, 4, 8, 2)
     b, _, _ = gpu_render(mrt, sc, None, 64, 36, 4, 8, 2)
     assert rmse_rgb(a, b) < 1e-4
+
+
+@pytest.mark.parametrize("scene", ["default", "cover-glass"])
+def test_counter_rng_mode(mrt, oracle, scene):
+    """Extension (north_star's counter-based RNG): per-sample states hashed from (pixel frame state, sample
+    index).  Same parity bar: bit-identical to the oracle in that mode, and a different image from mode 0."""
+    if scene == "default":
+        sc, cam, args = mrt.scene_default(), None, (96, 54, 8, 8)
+    else:
+        sc, cam = mrt.scene_cover(1, True)
+        args = (96, 54, 6, 50)
+    cnt = oracle.Counters()
+    ref = oracle_render(oracle, sc, cam, *args, seed=2, frames=2, counters=cnt, rng_mode=1)
+    got, c, _ = gpu_render(mrt, sc, cam, *args, seed=2, frames=2, rng_mode=1)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    assert c["rng_draws"] == cnt.rng_draws and c["world_hit_calls"] == cnt.world_hit_calls
+    other, _, _ = gpu_render(mrt, sc, cam, *args, seed=2, frames=2, rng_mode=0)
+    assert not np.array_equal(other, got)
+    assert rmse_rgb(other, got) < 0.2          # same picture, different noise

@@ -164,3 +164,19 @@ def test_golden_c1_lowres(oracle):
         got, counters = render_case(oracle, case)
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), case["name"]
         assert counters == case["counters"], case["name"]
+
+
+def test_counter_mode_sample_states(oracle):
+    """Extension: per-sample states depend only on (pixel frame state, sample index)."""
+    import ctypes as C
+    base = (C.c_uint32 * 4)(1, 2, 3, 4)
+    a, b, c = (C.c_uint32 * 4)(), (C.c_uint32 * 4)(), (C.c_uint32 * 4)()
+    oracle.lib().orc_sample_state.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
+    oracle.lib().orc_sample_state(base, 0, a)
+    oracle.lib().orc_sample_state(base, 1, b)
+    oracle.lib().orc_sample_state(base, 0, c)
+    assert list(a) == list(c) and list(a) != list(b) and any(a)
+    # murmur3 fmix32 of (1 + 0x9E3779B9 * 1)
+    z = (1 + 0x9E3779B9) & 0xFFFFFFFF
+    z ^= z >> 16; z = (z * 0x85EBCA6B) & 0xFFFFFFFF; z ^= z >> 13; z = (z * 0xC2B2AE35) & 0xFFFFFFFF; z ^= z >> 16
+    assert a[0] == z
