@@ -441,11 +441,10 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                         if (full) test8(gb, o, ds, bits);
                         // 16 (or 8) signs, sphere i at bit 15; candidate = discriminant >= 0
                         const uint32_t m = full ? (~bits & 0xFFFFu) : ((~bits & 0xFFu) << 8);
-                        MRT_STAMP(1);
                         masks[c * 64u] = (uint16_t)m;
                         nz |= (m < 1u ? m : 1u) << c;
-                        MRT_STAMP(2);
                     }
+                    MRT_STAMP(1);
                     if (weird) nz = 0;                    // such lanes take the literal loop below instead
                     // Walk, phase A: every lane goes through its own candidate clusters and evaluates the
                     // reference's discriminant (shader.wgsl:274-282) for their members; the few members
@@ -483,6 +482,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                             }
                         }
                     }
+                    MRT_STAMP(2);
                     // Walk, phase B: the reference's sqrt / divide / range tests (shader.wgsl:286-296) for
                     // the listed members; trips = the largest list in the wave.
                     for (uint32_t k = 0; k < lcnt; k++) {
