@@ -73,7 +73,7 @@ struct mrt_ctx {
     hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
     bool inputs_dirty = true;
     uint64_t frame_seq = 0;
-    uint32_t tiles_x = 0, n_tiles = 0, n_waves = 0;
+    uint32_t tiles_x = 0, n_tiles = 0, n_waves = 0, cus = 0;
     uint32_t pilot_spp = 2;
     int waves_per_cu_override = 0;
     bool lpt_enabled = true;
@@ -173,6 +173,7 @@ int alloc_frame_buffers(mrt_ctx* c) {
         if (mrt::render_waves_per_cu(&wpc) != 0 || wpc <= 0) wpc = 16;
         if (c->waves_per_cu_override > 0) wpc = c->waves_per_cu_override;
         c->n_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)wpc;
+        c->cus = (uint32_t)prop.multiProcessorCount;
     }
     int e = mrt::launch_fill_seeds(c->d_seeds, c->seed, c->args.width, c->args.height, c->shard_rank,
                                    c->shard_world, c->local_bands, c->stream);
@@ -685,6 +686,7 @@ int mrt_redraw(mrt_ctx* c) {
     p.n_spheres = c->n_spheres;
     p.n_padded = c->n_padded;
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
+    p.cus = c->cus;
     p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.members = c->d_members; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
     p.seeds = c->d_seeds;
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)

@@ -239,20 +239,31 @@ __device__ __forceinline__ KArgPtr cold_args() {
     return p;
 }
 
-template <bool COUNT, bool PILOT, bool CTR>
-__global__ void __launch_bounds__(64) render_kernel(const KParams P) {
-    __shared__ uint16_t mask_lds[kBlockChunks * 64];
-    __shared__ uint32_t ring[kRingCap];       // FIFO of waiting pixels: tile << 6 | lane-in-tile
-    __shared__ uint16_t list_lds[kListCap * 64];
-    uint16_t* const list = list_lds + threadIdx.x;            // entry k at list[k*64]: member index within the block
-    const uint32_t lane = threadIdx.x;
-    uint16_t* const masks = mask_lds + lane;                  // chunk c at masks[c*64]
+// A workgroup is kWavesPerGroup INDEPENDENT waves (each with its own FIFO, masks and list); they share
+// one thing: when the scene is small enough (LDSM), a read-only LDS copy of the member records that
+// the walk gathers per lane -- an L1 round trip per candidate cluster otherwise.
+constexpr uint32_t kWavesPerGroup = 4;
+template <bool COUNT, bool PILOT, bool CTR, bool LDSM>
+__global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KParams P) {
+    __shared__ uint16_t mask_lds[kWavesPerGroup][kBlockChunks * 64];
+    __shared__ uint32_t ring_lds[kWavesPerGroup][kRingCap];   // FIFO of waiting pixels: tile << 6 | lane-in-tile
+    __shared__ uint16_t list_lds[kWavesPerGroup][kListCap * 64];
+    extern __shared__ SphereRec lds_members[];                // LDSM: n_padded * kClusterK records
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint16_t* const list = list_lds[wave] + lane;             // entry k at list[k*64]: member index within the block
+    uint32_t* const ring = ring_lds[wave];
+    uint16_t* const masks = mask_lds[wave] + lane;            // chunk c at masks[c*64]
+    if (LDSM) {
+        const uint32_t n_rec = P.n_padded * kClusterK;
+        for (uint32_t i = threadIdx.x; i < n_rec; i += 64u * kWavesPerGroup) lds_members[i] = P.members[i];
+        __syncthreads();
+    }
 
     const uint32_t H = P.locals.shape[1];
     const uint32_t spp = PILOT ? P.pilot_spp : P.locals.samples_per_frame;
     const uint32_t n_padded = P.n_padded;
     const SphereRec* __restrict__ spheres = P.spheres;
-    const SphereRec* __restrict__ members = P.members;
+    const SphereRec* __restrict__ members = LDSM ? lds_members : P.members;
     const uint32_t* __restrict__ member_index = P.member_index;
     const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.clusters;
     const float pixel_side = 2.0f / (float)H;                 // fs_main :373
@@ -283,6 +294,7 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
 
 #ifdef MRT_STAMPS
     uint64_t phase_[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t trips_a_ = 0, trips_b_ = 0, lanes_a_ = 0, lanes_b_ = 0;
     uint64_t last_ = __builtin_amdgcn_s_memtime();
     const uint64_t wave_t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -451,7 +463,13 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                     // with disc >= 0 go on the lane's short list in LDS.  One cluster of every lane that
                     // still has one per trip.
                     uint32_t m = 0, base = 0, lcnt = 0;
+#ifdef MRT_STAMPS
+                    uint32_t la_ = 0;
+#endif
                     while ((nz | m) != 0u) {
+#ifdef MRT_STAMPS
+                        la_++;
+#endif
                         if (m == 0u) {
                             const uint32_t cc = (uint32_t)__builtin_ctz(nz);
                             nz &= nz - 1u;
@@ -482,6 +500,10 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
                             }
                         }
                     }
+#ifdef MRT_STAMPS
+                    { uint32_t k_ = 0; while (__any(la_ > k_)) k_++; trips_a_ += k_; lanes_a_ += la_;
+                      k_ = 0; while (__any(lcnt > k_)) k_++; trips_b_ += k_; lanes_b_ += lcnt; }
+#endif
                     MRT_STAMP(2);
                     // Walk, phase B: the reference's sqrt / divide / range tests (shader.wgsl:286-296) for
                     // the listed members; trips = the largest list in the wave.
@@ -587,6 +609,10 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
             c2 += __shfl_xor(c2, off);
             c4 += __shfl_xor(c4, off);
         }
+#ifdef MRT_STAMPS
+        unsigned long long lx_ = lanes_a_, ly_ = lanes_b_;
+        for (int off = 32; off > 0; off >>= 1) { lx_ += __shfl_xor(lx_, off); ly_ += __shfl_xor(ly_, off); }
+#endif
         if (lane == 0 && P.counters) {
             atomicAdd(P.counters + 0, c0);
             atomicAdd(P.counters + 1, c1);
@@ -595,8 +621,11 @@ __global__ void __launch_bounds__(64) render_kernel(const KParams P) {
             atomicAdd(P.counters + 4, c4);
 #ifdef MRT_STAMPS
             for (int k = 0; k < 6; k++) atomicAdd(P.counters + 6 + k, (unsigned long long)phase_[k]);
+            atomicAdd(P.counters + 12, (unsigned long long)trips_a_);
+            atomicAdd(P.counters + 13, (unsigned long long)trips_b_);
+            atomicAdd(P.counters + 14, lx_); atomicAdd(P.counters + 15, ly_);
             if (P.wave_log) {
-                unsigned long long* wl = P.wave_log + 4ull * blockIdx.x;
+                unsigned long long* wl = P.wave_log + 4ull * (blockIdx.x * kWavesPerGroup + wave);
                 wl[0] = wave_t0_; wl[1] = __builtin_amdgcn_s_memrealtime(); wl[2] = trips; wl[3] = c1;
             }
 #endif
@@ -670,25 +699,49 @@ __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64
 
 }  // namespace
 
+// LDS copy of the member records: only when it leaves room for 5 workgroups (20 waves) per CU,
+// below which throughput starts to fall
+static bool members_fit_lds(const KParams& p, size_t* bytes) {
+    *bytes = (size_t)p.n_padded * kClusterK * sizeof(SphereRec);
+    return *bytes <= 12 * 1024;
+}
+
 // queue reset + the persistent render waves (pilot: + its cost-only finalize) on `stream`
 int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) {
     if (p.n_tiles == 0 || n_waves == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
-    dim3 grid(n_waves < p.n_tiles ? n_waves : p.n_tiles), block(64);
-    const bool ctr = p.locals.rng_mode == MRT_RNG_COUNTER;
-    if (pilot) {
-        if (ctr) hipLaunchKernelGGL((render_kernel<false, true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((render_kernel<false, true, false>), grid, block, 0, st, p);
-        hipLaunchKernelGGL((finalize_kernel<true>), dim3(p.n_tiles), block, 0, st, p);
-    } else if (ctr) {
-        hipLaunchKernelGGL((render_kernel<true, false, true>), grid, block, 0, st, p);
-    } else if (p.counters) {
-        hipLaunchKernelGGL((render_kernel<true, false, false>), grid, block, 0, st, p);
-    } else {
-        hipLaunchKernelGGL((render_kernel<false, false, false>), grid, block, 0, st, p);
+    size_t lds = 0;
+    const bool ldsm = members_fit_lds(p, &lds);
+    if (!ldsm) lds = 0;
+    // persistent grid: as many workgroups as are resident with this variant's LDS footprint
+    // (n_waves comes from the occupancy of the variant without the LDS copy)
+    if (ldsm) {
+        const uint32_t static_lds = kWavesPerGroup * (kBlockChunks * 64 * 2 + kRingCap * 4 + kListCap * 64 * 2);
+        const uint32_t per_cu = (160u * 1024u) / (static_lds + (uint32_t)lds);
+        const uint32_t cap = p.cus * per_cu * kWavesPerGroup;
+        if (cap < n_waves) n_waves = cap;
     }
+    const uint32_t want = n_waves < p.n_tiles ? n_waves : p.n_tiles;
+    dim3 grid((want + kWavesPerGroup - 1) / kWavesPerGroup), block(64 * kWavesPerGroup);
+    const bool ctr = p.locals.rng_mode == MRT_RNG_COUNTER;
+#define MRT_LAUNCH(C_, P_, R_)                                                                        \
+    do {                                                                                              \
+        if (ldsm) hipLaunchKernelGGL((render_kernel<C_, P_, R_, true>), grid, block, lds, st, p);     \
+        else hipLaunchKernelGGL((render_kernel<C_, P_, R_, false>), grid, block, 0, st, p);           \
+    } while (0)
+    if (pilot) {
+        if (ctr) MRT_LAUNCH(false, true, true); else MRT_LAUNCH(false, true, false);
+        hipLaunchKernelGGL((finalize_kernel<true>), dim3(p.n_tiles), dim3(64), 0, st, p);
+    } else if (ctr) {
+        MRT_LAUNCH(true, false, true);
+    } else if (p.counters) {
+        MRT_LAUNCH(true, false, false);
+    } else {
+        MRT_LAUNCH(false, false, false);
+    }
+#undef MRT_LAUNCH
     return (int)hipGetLastError();
 }
 
@@ -702,8 +755,8 @@ int launch_finalize(const KParams& p, void* stream) {
 // how many waves of the render kernel one CU holds (occupancy API)
 int render_waves_per_cu(int* out) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false, false>, 64, 0);
-    *out = nb;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false, false, false>, 64 * kWavesPerGroup, 0);
+    *out = nb * (int)kWavesPerGroup;
     return (int)e;
 }
 

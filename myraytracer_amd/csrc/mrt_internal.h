@@ -28,6 +28,7 @@ struct KParams {
     uint32_t n_spheres;         // world.spheres.length
     uint32_t n_padded;          // cluster records, multiple of kGroup
     uint32_t shard_rank, shard_world;
+    uint32_t cus;               // compute units of the device (host-side launch sizing only)
     const SphereRec* spheres;   // n_spheres records in the reference's order (exact tests)
     // The discriminant sweep runs over CLUSTER records: the bounding sphere (cx,cy,cz,-R^2) of up to
     // kClusterK spatially close spheres, n_padded of them (multiple of kGroup, padded with never-hit

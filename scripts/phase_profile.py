@@ -21,3 +21,6 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     print("kernel ms", st.last_kernel_ms(), "wave sweeps", raw[3] / 64)
     for n, v in zip(names, ph):
         print(f"{n:32s} {v / max(1, tot):7.3%}  cycles/wave-iteration {v / (raw[3] / 64):9.1f}")
+    sweeps = raw[3] / 64
+    print(f"walk A: wave trips/sweep {raw[12] / sweeps:.2f}, mean lane trips/sweep {raw[14] / max(1, raw[1]):.2f}")
+    print(f"walk B: wave trips/sweep {raw[13] / sweeps:.2f}, mean lane trips/sweep {raw[15] / max(1, raw[1]):.2f}")
