@@ -685,6 +685,7 @@ int mrt_redraw(mrt_ctx* c) {
     p.cam = c->cam_raw;
     p.n_spheres = c->n_spheres;
     p.n_padded = c->n_padded;
+    { const uint32_t ch = (c->n_padded + mrt::kChunk - 1) / mrt::kChunk; p.mask_chunks = ch < 16u ? ch : 16u; }
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.cus = c->cus;
     p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.members = c->d_members; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;

@@ -205,8 +205,42 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 #define MRT_STAMP(k) do { } while (0)
 #endif
 
-constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 spheres between walks
-constexpr uint32_t kListCap = 16;         // per-lane list of members whose discriminant is >= 0
+constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 spheres per sweep block
+
+// The cooperative walk: candidates found by the sweep become wave-wide work items
+// (owner lane, node) in small LDS queues; every round 64 lanes take 64 items, whoever owns them.
+//   queue kLevels : (owner, cluster)  written by the owners from their sweep masks
+//   queue 0       : (owner, member)   members whose discriminant is >= 0, waiting for the root tests
+constexpr int kLevels = 1;                // cooperative levels above the member spheres
+constexpr uint32_t kGenCap = 576;         // capacity of the top queue
+constexpr uint32_t kQueueCap = 320;       // lower queues: < 64 left over + 4 x 64 pushed by one round
+constexpr unsigned long long kNoHitKey = 0x461C4000FFFFFFFFull;   // (bits(1e4f) << 32) | -1
+
+template <bool SMALL> struct Ent;
+template <> struct Ent<true>  { typedef uint16_t type; static constexpr uint32_t id_bits = 10u; };
+template <> struct Ent<false> { typedef uint32_t type; static constexpr uint32_t id_bits = 26u; };
+
+// LDS of one wave: hit slots, rays, pixel FIFO, work queues, candidate masks
+__host__ __device__ constexpr uint32_t lds_off_rays() { return 0u; }                   // 64 x {ox,oy,oz,dx | dy,dz, u64 hit slot}
+__host__ __device__ constexpr uint32_t lds_off_ring() { return 2048u; }                // kRingCap x u32
+__host__ __device__ constexpr uint32_t lds_off_queues() { return 2048u + 512u; }
+__host__ __device__ constexpr uint32_t lds_queue_bytes(bool small) { return (kLevels * kQueueCap + kGenCap) * (small ? 2u : 4u); }
+__host__ __device__ constexpr uint32_t lds_off_masks(bool small) { return lds_off_queues() + lds_queue_bytes(small); }
+__host__ __device__ constexpr uint32_t lds_wave_bytes(bool small, uint32_t mask_chunks) { return lds_off_masks(small) + mask_chunks * 128u; }
+
+// inclusive prefix sum over the 64 lanes of a wave (all lanes active)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+#define MRT_DPP_ADD(ctrl, rmask) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xF, false)
+    MRT_DPP_ADD(0x111, 0xF);      // row_shr:1
+    MRT_DPP_ADD(0x112, 0xF);      // row_shr:2
+    MRT_DPP_ADD(0x114, 0xF);      // row_shr:4
+    MRT_DPP_ADD(0x118, 0xF);      // row_shr:8   -> scan within each row of 16
+    MRT_DPP_ADD(0x142, 0xA);      // row_bcast:15 into rows 1 and 3
+    MRT_DPP_ADD(0x143, 0xC);      // row_bcast:31 into rows 2 and 3
+#undef MRT_DPP_ADD
+    return x;
+}
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }   // compiler-level only: LDS runs a wave's accesses in order
 
 // lanes below `lane` whose bit is set in the 64-bit ballot `mask`
 __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
@@ -239,23 +273,29 @@ __device__ __forceinline__ KArgPtr cold_args() {
     return p;
 }
 
-// A workgroup is kWavesPerGroup INDEPENDENT waves (each with its own FIFO, masks and list); they share
-// one thing: when the scene is small enough (LDSM), a read-only LDS copy of the member records that
-// the walk gathers per lane -- an L1 round trip per candidate cluster otherwise.
+// A workgroup is kWavesPerGroup INDEPENDENT waves (each with its own FIFO, masks, queues); they share
+// one thing: when the scene is small enough (SMALL), a read-only LDS copy of the member records that
+// the walk gathers per item -- an L1 round trip per candidate cluster otherwise.  SMALL also means
+// that every node id fits 10 bits, so the work items are u16.
 constexpr uint32_t kWavesPerGroup = 4;
-template <bool COUNT, bool PILOT, bool CTR, bool LDSM>
+template <bool COUNT, bool PILOT, bool CTR, bool SMALL>
 __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KParams P) {
-    __shared__ uint16_t mask_lds[kWavesPerGroup][kBlockChunks * 64];
-    __shared__ uint32_t ring_lds[kWavesPerGroup][kRingCap];   // FIFO of waiting pixels: tile << 6 | lane-in-tile
-    __shared__ uint16_t list_lds[kWavesPerGroup][kListCap * 64];
-    extern __shared__ SphereRec lds_members[];                // LDSM: n_padded * kClusterK records
+    typedef typename Ent<SMALL>::type entry_t;
+    constexpr uint32_t kIdBits = Ent<SMALL>::id_bits;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint16_t* const list = list_lds[wave] + lane;             // entry k at list[k*64]: member index within the block
-    uint32_t* const ring = ring_lds[wave];
-    uint16_t* const masks = mask_lds[wave] + lane;            // chunk c at masks[c*64]
-    if (LDSM) {
+    const uint32_t nodes_bytes = SMALL ? P.n_padded * kClusterK * (uint32_t)sizeof(SphereRec) : 0u;
+    unsigned char* const wlds = lds_raw + nodes_bytes + wave * lds_wave_bytes(SMALL, P.mask_chunks);
+    // lane l's 32 bytes: (ox,oy,oz,dx) (dy,dz) and the u64 slot its closest hit is min-ed into
+    float4* const rays = reinterpret_cast<float4*>(wlds + lds_off_rays());
+    unsigned long long* const best_slots = reinterpret_cast<unsigned long long*>(wlds + lds_off_rays()) + 3;   // slot of lane l at [4*l]
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(wlds + lds_off_ring());     // FIFO of waiting pixels: tile << 6 | lane-in-tile
+    entry_t* const queues = reinterpret_cast<entry_t*>(wlds + lds_off_queues());   // queue k at k * kQueueCap
+    uint16_t* const masks = reinterpret_cast<uint16_t*>(wlds + lds_off_masks(SMALL)) + lane;   // chunk c at masks[c*64]
+    if (SMALL) {
+        SphereRec* const dst = reinterpret_cast<SphereRec*>(lds_raw);
         const uint32_t n_rec = P.n_padded * kClusterK;
-        for (uint32_t i = threadIdx.x; i < n_rec; i += 64u * kWavesPerGroup) lds_members[i] = P.members[i];
+        for (uint32_t i = threadIdx.x; i < n_rec; i += 64u * kWavesPerGroup) dst[i] = P.members[i];
         __syncthreads();
     }
 
@@ -263,7 +303,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
     const uint32_t spp = PILOT ? P.pilot_spp : P.locals.samples_per_frame;
     const uint32_t n_padded = P.n_padded;
     const SphereRec* __restrict__ spheres = P.spheres;
-    const SphereRec* __restrict__ members = LDSM ? lds_members : P.members;
+    const SphereRec* members = SMALL ? reinterpret_cast<const SphereRec*>(lds_raw) : P.members;
     const uint32_t* __restrict__ member_index = P.member_index;
     const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.clusters;
     const float pixel_side = 2.0f / (float)H;                 // fs_main :373
@@ -290,11 +330,12 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
     uint32_t base0 = 0, base1 = 0, base2 = 0, base3 = 0;     // CTR: the pixel's frame state, hashed per sample
     V3 color = v3(0.0f, 0.0f, 0.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, -1.0f), att = v3(1.0f, 1.0f, 1.0f);
-    uint32_t depth_left = 0, started = 0, bounces = 0, trips = 0, mtests = 0;
+    uint32_t depth_left = 0, started = 0, bounces = 0, trips = 0;
+    unsigned long long mtests = 0;       // wave-uniform
 
 #ifdef MRT_STAMPS
     uint64_t phase_[6] = {0, 0, 0, 0, 0, 0};
-    uint64_t trips_a_ = 0, trips_b_ = 0, lanes_a_ = 0, lanes_b_ = 0;
+    uint64_t rounds_a_ = 0, rounds_b_ = 0, items_a_ = 0, items_b_ = 0;     // wave-uniform
     uint64_t last_ = __builtin_amdgcn_s_memtime();
     const uint64_t wave_t0_ = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -364,7 +405,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
         trips++;
         MRT_STAMP(5);
 
-        if (has_task && !task_done) {
+        const bool live = has_task && !task_done;
+        if (live) {
             pix_trips++;
             if (need_sample) {
                 if (CTR) {      // extension: this sample's state = hash(pixel frame state, sample index)
@@ -411,116 +453,213 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                 started++;
                 need_sample = false;
             }
-            MRT_STAMP(0);
+        }
+        MRT_STAMP(0);
 
-            bool path_done = false;
-            V3 contrib = v3(0.0f, 0.0f, 0.0f);
+        // ------------------------------------------------------------ world_hit, shader.wgsl:314-329
+        const bool trace = live && depth_left != 0u;                        // lanes inside the loop of :339
+        float t_sup = 1.0e4f;                                               // :340
+        int32_t best = -1;
+        if (__any(trace)) {
+            const float a = dot3(d, d);                                     // sphere_hit :277 (same for every sphere)
+            // A ray with a non-finite component makes every discriminant NaN, which the
+            // reference treats as "not < 0".  Such lanes take the literal loop below.
+            // So does a direction that is not (nearly) unit length -- normalize() of an overflowed or
+            // zero vector -- for which the sweep's conservative test has no proof.
+            const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
+                                 __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff()) ||
+                               !(a > 0.99999f && a < 1.00001f);
+            const bool usable = trace && !weird;
+            const V3 ds = v3(d.x * 1.00003f, d.y * 1.00003f, d.z * 1.00003f);
+            // every lane leaves its ray where whoever picks up one of its work items finds it
+            rays[2u * lane + 0u] = make_float4(o.x, o.y, o.z, d.x);
+            rays[2u * lane + 1u] = make_float4(d.y, d.z, __uint_as_float((uint32_t)kNoHitKey), __uint_as_float((uint32_t)(kNoHitKey >> 32)));
+            lds_order();
+            // Conservative sweep + cooperative walk, in blocks of kBlockChunks x kChunk cluster records.
+            // The records are wave-uniform: they are fetched with scalar loads, 8 records (two
+            // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
+            // loads of group g+1, then run the 8 x 11 VALU ops of group g while they fly.
+            Sph8 ga, gb;
+            smem_load8(ga, sph_quads, 0u);
+            asm volatile("" : "=s"(gb.lo), "=s"(gb.hi));   // defined (uniform) on every path to the final wait
+            uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
+            for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
+                const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
+                uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
+                uint32_t rem = 0;                                       // this lane's candidate clusters in the block
+                uint32_t c = 0;
+                for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
+                    // the record count is padded to 8, not 16: the very last chunk may hold one group only
+                    const bool full = i + 8u < n_padded;
+                    smem_wait_then_load8(ga, gb, sph_quads, full ? i + 8u : 0u, bits);  test8(ga, o, ds, bits);
+                    const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
+                    smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);
+                    if (full) test8(gb, o, ds, bits);
+                    // 16 (or 8) signs, record i at bit 15; candidate = S >= 0
+                    const uint32_t m = full ? (~bits & 0xFFFFu) : ((~bits & 0xFFu) << 8);
+                    masks[c * 64u] = (uint16_t)m;
+                    nz |= (m < 1u ? m : 1u) << c;
+                    rem += (uint32_t)__builtin_popcount(m);
+                }
+                MRT_STAMP(1);
+                if (!usable) { nz = 0; rem = 0; }         // idle lanes; "weird" lanes take the literal loop below
+                lds_order();
 
-            if (depth_left == 0u) {
-                path_done = true;                                           // loop :339 not entered -> :357
-            } else {
-                // ------------------------------------------------ world_hit, shader.wgsl:314-329
-                bounces++;
-                const float a = dot3(d, d);                                 // sphere_hit :277 (same for every sphere)
-                float t_sup = 1.0e4f;                                       // :340
-                int32_t best = -1;
-                // A ray with a non-finite component makes every discriminant NaN, which the
-                // reference treats as "not < 0".  Such lanes take the literal loop below.
-                // So does a direction that is not (nearly) unit length -- normalize() of an overflowed or
-                // zero vector -- for which the sweep's conservative test has no proof.
-                const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
-                                     __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff()) ||
-                                   !(a > 0.99999f && a < 1.00001f);
-                const V3 ds = v3(d.x * 1.00003f, d.y * 1.00003f, d.z * 1.00003f);
-                // Discriminant sweep + exact pass, in blocks of kBlockChunks x kChunk spheres.
-                // Sphere records are wave-uniform: they are fetched with scalar loads, 8 records (two
-                // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
-                // loads of group g+1, then run the 8 x 12 VALU ops of group g while they fly.
-                Sph8 ga, gb;
-                smem_load8(ga, sph_quads, 0u);
-                asm volatile("" : "=s"(gb.lo), "=s"(gb.hi));   // defined (uniform) on every path to the final wait
-                uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
-                for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
-                    const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
-                    uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
-                    uint32_t c = 0;
-                    for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
-                        // the sphere count is padded to 8, not 16: the very last chunk may hold one group only
-                        const bool full = i + 8u < n_padded;
-                        smem_wait_then_load8(ga, gb, sph_quads, full ? i + 8u : 0u, bits);  test8(ga, o, ds, bits);
-                        const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
-                        smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);
-                        if (full) test8(gb, o, ds, bits);
-                        // 16 (or 8) signs, sphere i at bit 15; candidate = discriminant >= 0
-                        const uint32_t m = full ? (~bits & 0xFFFFu) : ((~bits & 0xFFu) << 8);
-                        masks[c * 64u] = (uint16_t)m;
-                        nz |= (m < 1u ? m : 1u) << c;
-                    }
-                    MRT_STAMP(1);
-                    if (weird) nz = 0;                    // such lanes take the literal loop below instead
-                    // Walk, phase A: every lane goes through its own candidate clusters and evaluates the
-                    // reference's discriminant (shader.wgsl:274-282) for their members; the few members
-                    // with disc >= 0 go on the lane's short list in LDS.  One cluster of every lane that
-                    // still has one per trip.
-                    uint32_t m = 0, base = 0, lcnt = 0;
-#ifdef MRT_STAMPS
-                    uint32_t la_ = 0;
-#endif
-                    while ((nz | m) != 0u) {
-#ifdef MRT_STAMPS
-                        la_++;
-#endif
-                        if (m == 0u) {
-                            const uint32_t cc = (uint32_t)__builtin_ctz(nz);
-                            nz &= nz - 1u;
-                            m = masks[cc * 64u];
-                            base = blk + cc * kChunk;
-                        }
-                        const uint32_t j = (uint32_t)__builtin_clz(m) - 16u;
-                        m &= ~(0x8000u >> j);
-                        const uint32_t first = (base + j) * kClusterK;
-                        if (COUNT) mtests += kClusterK;
-                        if (lcnt > kListCap - kClusterK) {       // rare: make room (phase B for this lane now)
-                            for (uint32_t k = 0; k < lcnt; k++) {
-                                const uint32_t mi = blk * kClusterK + list[k * 64u];
-                                exact_test(members[mi], member_index[mi], o, d, a, t_sup, best);
+                // ---- cooperative walk over this block's candidates
+                uint32_t wm = 0, wfirst = 0;              // owner side: the chunk mask being unpacked, its first cluster id
+                uint32_t incl = wave_incl_scan(rem);
+                uint32_t total_rem = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t qn[kLevels + 1];
+#pragma unroll
+                for (int lv = 0; lv <= kLevels; lv++) qn[lv] = 0u;
+                for (;;) {
+                    // a full round at the deepest level that has one; else refill the top queue; else
+                    // a partial round at the highest level that has anything
+                    int k = -1;
+#pragma unroll
+                    for (int lv = 0; lv <= kLevels; lv++) if (k < 0 && qn[lv] >= 64u) k = lv;
+                    if (k < 0) {
+                        if (total_rem != 0u) {
+                            // owners unpack their masks into (owner, cluster) items at their scanned positions
+                            const uint32_t excl = incl - rem;
+                            const uint32_t room = kGenCap - qn[kLevels];
+                            const uint32_t n_new = total_rem < room ? total_rem : room;
+                            entry_t* const dst = queues + kLevels * kQueueCap + qn[kLevels];
+                            uint32_t p = excl;
+                            while ((nz | wm) != 0u && p < n_new) {
+                                if (wm == 0u) {
+                                    const uint32_t cc = (uint32_t)__builtin_ctz(nz);
+                                    nz &= nz - 1u;
+                                    wm = masks[cc * 64u];
+                                    wfirst = blk + cc * kChunk;
+                                }
+                                const uint32_t j = (uint32_t)__builtin_clz(wm) - 16u;
+                                wm &= ~(0x8000u >> j);
+                                dst[p] = (entry_t)((lane << kIdBits) | (wfirst + j));
+                                p++;
                             }
-                            lcnt = 0;
+                            rem -= p - excl;
+                            qn[kLevels] += n_new;
+                            total_rem -= n_new;
+                            if (total_rem != 0u) incl = wave_incl_scan(rem);
+                            lds_order();
+                            MRT_STAMP(2);
+                            continue;
                         }
 #pragma unroll
-                        for (uint32_t k = 0; k < kClusterK; k++) {
-                            const SphereRec s = members[first + k];
-                            const float ocx = o.x - s.cx, ocy = o.y - s.cy, ocz = o.z - s.cz;
-                            const float b = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));
-                            const float c = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, s.neg_r2)));
-                            const float disc = __builtin_fmaf(b, b, -(a * c));
-                            if (!(disc < 0.0f)) {
-                                list[lcnt * 64u] = (uint16_t)(first + k - blk * kClusterK);
-                                lcnt++;
+                        for (int lv = kLevels; lv >= 0; lv--) if (k < 0 && qn[lv] != 0u) k = lv;
+                        if (k < 0) break;
+                    }
+                    uint32_t n = 0;
+#pragma unroll
+                    for (int lv = 0; lv <= kLevels; lv++) n = (k == lv) ? qn[lv] : n;
+                    const uint32_t take = n < 64u ? n : 64u, start = n - take;
+                    const bool act = lane < take;
+                    const entry_t* const src = queues + (uint32_t)k * kQueueCap;
+                    const uint32_t it = src[act ? start + lane : 0u];
+                    const uint32_t owner = it >> kIdBits, node = it & ((1u << kIdBits) - 1u);
+                    const float4 r0 = rays[2u * owner];
+                    const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
+                    const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r0.w, r1.x, r1.y);
+                    const float ra = dot3(rd, rd);                      // the owner's `a`, same expression
+                    if (k != 0) {
+                        // node round: the reference's discriminant (shader.wgsl:274-282) for the 4 members of
+                        // each item's cluster; members with disc >= 0 become (owner, member) items
+                        // read q takes member (q + node/4) % 4, so that the 64 lanes of one read spread
+                        // over all 16 LDS slots (4 banks each) instead of the 4 that member q alone maps to
+                        const SphereRec* const ch = members + 4u * node;
+                        const uint32_t rot = node >> 2;
+                        bool h[4];
+                        {
+                            const SphereRec sr[4] = {ch[rot & 3u], ch[(rot + 1u) & 3u], ch[(rot + 2u) & 3u], ch[(rot + 3u) & 3u]};
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const float ocx = ro.x - sr[q].cx, ocy = ro.y - sr[q].cy, ocz = ro.z - sr[q].cz;
+                                const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
+                                const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sr[q].neg_r2)));
+                                const float disc = __builtin_fmaf(bq, bq, -(ra * cq));
+                                h[q] = act && !(disc < 0.0f);
                             }
                         }
-                    }
+                        uint32_t dn = 0;
+#pragma unroll
+                        for (int lv = 0; lv < kLevels; lv++) dn = (k - 1 == lv) ? qn[lv] : dn;
+                        entry_t* const dst = queues + (uint32_t)(k - 1) * kQueueCap + dn;
+                        const uint32_t e0 = (owner << kIdBits) | (4u * node);
+                        uint32_t pushed = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(h[q]);
+                            if (h[q]) dst[pushed + rank_in(mk)] = (entry_t)(e0 + ((rot + (uint32_t)q) & 3u));
+                            pushed += (uint32_t)__popcll(mk);
+                        }
+#pragma unroll
+                        for (int lv = 0; lv <= kLevels; lv++) {
+                            if (k == lv) qn[lv] = start;
+                            if (k - 1 == lv) qn[lv] += pushed;
+                        }
+                        if (COUNT) mtests += kClusterK * take;
 #ifdef MRT_STAMPS
-                    { uint32_t k_ = 0; while (__any(la_ > k_)) k_++; trips_a_ += k_; lanes_a_ += la_;
-                      k_ = 0; while (__any(lcnt > k_)) k_++; trips_b_ += k_; lanes_b_ += lcnt; }
+                        rounds_a_++; items_a_ += take;
 #endif
-                    MRT_STAMP(2);
-                    // Walk, phase B: the reference's sqrt / divide / range tests (shader.wgsl:286-296) for
-                    // the listed members; trips = the largest list in the wave.
-                    for (uint32_t k = 0; k < lcnt; k++) {
-                        const uint32_t mi = blk * kClusterK + list[k * 64u];
-                        exact_test(members[mi], member_index[mi], o, d, a, t_sup, best);
+                        lds_order();
+                        MRT_STAMP(2);
+                    } else {
+                        // root round: the reference's sqrt / divide / range tests (shader.wgsl:286-296).
+                        // Each member's root goes into its owner's slot by a 64-bit unsigned minimum of
+                        // (bits(t) << 32 | sphere index): t > 0, so this is the lexicographic minimum of
+                        // (t, index) over spheres with a root in [0.001, 1e4) -- what the reference's
+                        // index-order scan with `t_sup <= t` (:291-296) ends with (`near` is tried first,
+                        // `far` only if `near` is out of range: near >= t_sup implies far >= t_sup).
+                        const SphereRec sm = members[node];
+                        const uint32_t sidx = member_index[node];
+                        const float ocx = ro.x - sm.cx, ocy = ro.y - sm.cy, ocz = ro.z - sm.cz;
+                        const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
+                        const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sm.neg_r2)));
+                        const float disc = __builtin_fmaf(bq, bq, -(ra * cq));
+                        const float d_sqrt = __builtin_sqrtf(disc);                   // :286
+                        const float t_min = 0.001f;                                   // :340
+                        const float t_near = (-bq - d_sqrt) / ra;                     // :290
+                        const float t_far = (-bq + d_sqrt) / ra;                      // :292
+                        const bool ok_near = !(t_near < t_min) && t_near < 1.0e4f;
+                        const bool ok_far = !(t_far < t_min) && t_far < 1.0e4f;
+                        const float t = ok_near ? t_near : t_far;
+                        // (unconditional, with a key that changes nothing for lanes without a root: no branch
+                        // for the index load to hide behind)
+                        const unsigned long long key = (act && (ok_near || ok_far)) ? (((unsigned long long)__float_as_uint(t) << 32) | sidx) : kNoHitKey;
+                        atomicMin(best_slots + 4u * owner, key);
+                        qn[0] = start;
+#ifdef MRT_STAMPS
+                        rounds_b_++; items_b_ += take;
+#endif
+                        lds_order();
+                        MRT_STAMP(3);
                     }
                 }
-                // the last prefetches are never consumed, but their destination SGPRs must stay
-                // reserved until they have landed
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi), "+s"(gb.lo), "+s"(gb.hi));
+            }
+            // the last prefetches are never consumed, but their destination SGPRs must stay
+            // reserved until they have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi), "+s"(gb.lo), "+s"(gb.hi));
+            if (trace) {
                 if (weird) {
                     for (uint32_t idx = 0; idx < P.n_spheres; idx++)
                         literal_test(spheres[idx], idx, o, d, a, t_sup, best);
+                } else {
+                    const unsigned long long key = best_slots[4u * lane];
+                    t_sup = __uint_as_float((uint32_t)(key >> 32));
+                    best = (int32_t)(uint32_t)key;
                 }
-                MRT_STAMP(3);
+            }
+        }
+        MRT_STAMP(3);
 
+        if (live) {
+            bool path_done = false;
+            V3 contrib = v3(0.0f, 0.0f, 0.0f);
+            if (depth_left == 0u) {
+                path_done = true;                                           // loop :339 not entered -> :357
+            } else {
+                bounces++;
                 if (best < 0) {
                     // color_sky, shader.wgsl:331-334, 343-345
                     float t = 0.5f * d.y + 0.5f;
@@ -601,29 +740,25 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
     }
 
     if (COUNT && !PILOT) {
-        unsigned long long c0 = started, c1 = bounces, c2 = rng.draws, c4 = mtests;
+        unsigned long long c0 = started, c1 = bounces, c2 = rng.draws;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             c0 += __shfl_xor(c0, off);
             c1 += __shfl_xor(c1, off);
             c2 += __shfl_xor(c2, off);
-            c4 += __shfl_xor(c4, off);
         }
-#ifdef MRT_STAMPS
-        unsigned long long lx_ = lanes_a_, ly_ = lanes_b_;
-        for (int off = 32; off > 0; off >>= 1) { lx_ += __shfl_xor(lx_, off); ly_ += __shfl_xor(ly_, off); }
-#endif
         if (lane == 0 && P.counters) {
             atomicAdd(P.counters + 0, c0);
             atomicAdd(P.counters + 1, c1);
             atomicAdd(P.counters + 2, c2);
             atomicAdd(P.counters + 3, 64ull * trips);
-            atomicAdd(P.counters + 4, c4);
+            atomicAdd(P.counters + 4, (unsigned long long)mtests);     // wave-uniform
 #ifdef MRT_STAMPS
             for (int k = 0; k < 6; k++) atomicAdd(P.counters + 6 + k, (unsigned long long)phase_[k]);
-            atomicAdd(P.counters + 12, (unsigned long long)trips_a_);
-            atomicAdd(P.counters + 13, (unsigned long long)trips_b_);
-            atomicAdd(P.counters + 14, lx_); atomicAdd(P.counters + 15, ly_);
+            atomicAdd(P.counters + 12, (unsigned long long)rounds_a_);
+            atomicAdd(P.counters + 13, (unsigned long long)rounds_b_);
+            atomicAdd(P.counters + 14, (unsigned long long)items_a_);
+            atomicAdd(P.counters + 15, (unsigned long long)items_b_);
             if (P.wave_log) {
                 unsigned long long* wl = P.wave_log + 4ull * (blockIdx.x * kWavesPerGroup + wave);
                 wl[0] = wave_t0_; wl[1] = __builtin_amdgcn_s_memrealtime(); wl[2] = trips; wl[3] = c1;
@@ -699,11 +834,10 @@ __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64
 
 }  // namespace
 
-// LDS copy of the member records: only when it leaves room for 5 workgroups (20 waves) per CU,
-// below which throughput starts to fall
-static bool members_fit_lds(const KParams& p, size_t* bytes) {
-    *bytes = (size_t)p.n_padded * kClusterK * sizeof(SphereRec);
-    return *bytes <= 12 * 1024;
+// SMALL scenes (every node id < 1024): member records live in LDS and work items are u16
+static bool scene_is_small(const KParams& p) { return p.n_padded * kClusterK <= 1024u; }
+static uint32_t group_lds_bytes(const KParams& p, bool small) {
+    return (small ? p.n_padded * kClusterK * (uint32_t)sizeof(SphereRec) : 0u) + kWavesPerGroup * lds_wave_bytes(small, p.mask_chunks);
 }
 
 // queue reset + the persistent render waves (pilot: + its cost-only finalize) on `stream`
@@ -712,14 +846,12 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
-    size_t lds = 0;
-    const bool ldsm = members_fit_lds(p, &lds);
-    if (!ldsm) lds = 0;
-    // persistent grid: as many workgroups as are resident with this variant's LDS footprint
-    // (n_waves comes from the occupancy of the variant without the LDS copy)
-    if (ldsm) {
-        const uint32_t static_lds = kWavesPerGroup * (kBlockChunks * 64 * 2 + kRingCap * 4 + kListCap * 64 * 2);
-        const uint32_t per_cu = (160u * 1024u) / (static_lds + (uint32_t)lds);
+    const bool small = scene_is_small(p);
+    const uint32_t lds = group_lds_bytes(p, small);
+    // persistent grid: as many workgroups as are resident with this launch's LDS footprint
+    // (n_waves comes from the register-limited occupancy)
+    {
+        const uint32_t per_cu = (160u * 1024u) / lds;
         const uint32_t cap = p.cus * per_cu * kWavesPerGroup;
         if (cap < n_waves) n_waves = cap;
     }
@@ -728,8 +860,8 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
     const bool ctr = p.locals.rng_mode == MRT_RNG_COUNTER;
 #define MRT_LAUNCH(C_, P_, R_)                                                                        \
     do {                                                                                              \
-        if (ldsm) hipLaunchKernelGGL((render_kernel<C_, P_, R_, true>), grid, block, lds, st, p);     \
-        else hipLaunchKernelGGL((render_kernel<C_, P_, R_, false>), grid, block, 0, st, p);           \
+        if (small) hipLaunchKernelGGL((render_kernel<C_, P_, R_, true>), grid, block, lds, st, p);    \
+        else hipLaunchKernelGGL((render_kernel<C_, P_, R_, false>), grid, block, lds, st, p);         \
     } while (0)
     if (pilot) {
         if (ctr) MRT_LAUNCH(false, true, true); else MRT_LAUNCH(false, true, false);

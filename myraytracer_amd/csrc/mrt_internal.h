@@ -27,6 +27,7 @@ struct KParams {
     mrt_camera_raw cam;
     uint32_t n_spheres;         // world.spheres.length
     uint32_t n_padded;          // cluster records, multiple of kGroup
+    uint32_t mask_chunks;       // chunks of kChunk records per sweep block: min(16, ceil(n_padded / kChunk))
     uint32_t shard_rank, shard_world;
     uint32_t cus;               // compute units of the device (host-side launch sizing only)
     const SphereRec* spheres;   // n_spheres records in the reference's order (exact tests)
