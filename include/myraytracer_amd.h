@@ -225,6 +225,9 @@ int mrt_debug_read_pixel_costs(mrt_ctx* ctx, uint32_t* out, size_t cap);
 /* Diagnostic / tuning: growth factor of the sweep's sphere clusters (0 = one sphere per record),
  * used by the next mrt_set_world* call. */
 int mrt_debug_set_cluster_factor(mrt_ctx* ctx, float factor);
+/* Diagnostic / tuning: depth of the bounding-sphere hierarchy built by the next mrt_set_world* call:
+ * levels are added (up to max_levels, 1..4) while the top level has more than top_target records. */
+int mrt_debug_set_hierarchy(mrt_ctx* ctx, uint32_t max_levels, uint32_t top_target);
 /* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */
 int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);
 /* Diagnostic / tuning: pilot samples per pixel, waves per CU (0 = automatic).  Before the first

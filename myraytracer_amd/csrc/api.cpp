@@ -46,9 +46,12 @@ struct mrt_ctx {
     // device memory (all owned)
     mrt::SphereRec* d_spheres = nullptr;
     mrt::SphereRec* d_clusters = nullptr;  // bounding spheres the sweep tests (up to kClusterK spheres each)
-    mrt::SphereRec* d_members = nullptr;   // kClusterK member records per cluster
+    mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
     uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
     float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
+    uint32_t max_levels = mrt::kMaxLevels, top_target = 64;   // hierarchy depth rule (build_hierarchy)
+    uint32_t levels = 1, n_nodes = 0, n_members = 0;
+    uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
     float* d_vec4 = nullptr;
     float* d_f32 = nullptr;
     int32_t* d_i32 = nullptr;
@@ -134,12 +137,12 @@ void free_frame_buffers(mrt_ctx* c) {
 void free_world(mrt_ctx* c) {
     if (c->d_spheres) (void)hipFree(c->d_spheres);
     if (c->d_clusters) (void)hipFree(c->d_clusters);
-    if (c->d_members) (void)hipFree(c->d_members);
+    if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_member_index) (void)hipFree(c->d_member_index);
     if (c->d_vec4) (void)hipFree(c->d_vec4);
     if (c->d_f32) (void)hipFree(c->d_f32);
     if (c->d_i32) (void)hipFree(c->d_i32);
-    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_members = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
+    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
     c->have_world = false;
 }
 
@@ -299,6 +302,74 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
         clusters.push_back(never);                                    // S = -inf: never a candidate
         for (uint32_t m = 0; m < mrt::kClusterK; m++) { members.push_back(never); member_index.push_back(0u); }
     }
+}
+
+// Upper levels of the hierarchy: level k+1 bounds 4 consecutive level-k nodes (consecutive along the
+// Morton curve, so neighbours in space); its bounding sphere is measured from the MEMBER spheres under
+// it, R = 1.06 x the enclosing radius from the f32-rounded centre, so the conservativeness argument of
+// the clusters holds for every level.  Levels are added while the top has more than
+// top_target records (the sweep costs every ray one test per top record; a walk round costs about 1.5
+// wave-instructions per item).  Every level is padded to a multiple of 4 (the top: kGroup) with
+// never-hit records; the children of a never-hit node are never read.
+struct Hierarchy {
+    std::vector<mrt::SphereRec> top, nodes;
+    std::vector<uint32_t> member_index;
+    uint32_t levels = 1, n_members = 0;
+    uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
+};
+
+void build_hierarchy(const float* centers4, const float* radii, uint32_t n, float factor, uint32_t max_levels,
+                     uint32_t top_target, Hierarchy& H) {
+    const mrt::SphereRec never{0.0f, 0.0f, 0.0f, INFINITY};
+    std::vector<mrt::SphereRec> members, cur;
+    build_clusters(centers4, radii, n, factor, cur, members, H.member_index);
+    H.n_members = (uint32_t)members.size();
+    H.nodes = members;
+    H.levels = 1;
+    H.level_base[0] = 0;
+    // scenes whose members fit 10-bit ids (the kernel's SMALL variant) keep one level: with <= 256 clusters
+    // the sweep is cheap and the bounds of 16 spheres are loose (C3: a ray touches 10 of 38 such bounds)
+    if (H.n_members <= 1024u) max_levels = 1;
+    while (H.levels < max_levels && cur.size() > top_target) {
+        const size_t span = (size_t)1 << (2 * (H.levels + 1));        // members under one node of the new level
+        const size_t n_par = (cur.size() + 3) / 4;
+        std::vector<mrt::SphereRec> par;
+        par.reserve(n_par + mrt::kGroup);
+        for (size_t j = 0; j < n_par; j++) {
+            const size_t m0 = j * span, m1 = std::min(members.size(), (j + 1) * span);
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            bool any = false;
+            for (size_t m = m0; m < m1; m++) {
+                if (!std::isfinite(members[m].neg_r2)) continue;
+                const uint32_t i = H.member_index[m];
+                const double r = std::fabs((double)radii[i]);
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = std::min(lo[k], (double)centers4[4 * i + k] - r);
+                    hi[k] = std::max(hi[k], (double)centers4[4 * i + k] + r);
+                }
+                any = true;
+            }
+            if (!any) { par.push_back(never); continue; }
+            double ctr[3], R = 0;
+            for (int k = 0; k < 3; k++) ctr[k] = (double)(float)(0.5 * (lo[k] + hi[k]));
+            for (size_t m = m0; m < m1; m++) {
+                if (!std::isfinite(members[m].neg_r2)) continue;
+                const uint32_t i = H.member_index[m];
+                double d2 = 0;
+                for (int k = 0; k < 3; k++) { const double d = (double)centers4[4 * i + k] - ctr[k]; d2 += d * d; }
+                R = std::max(R, std::sqrt(d2) + std::fabs((double)radii[i]));
+            }
+            const float Rf = (float)(R * 1.06) + 1e-30f;
+            par.push_back(mrt::SphereRec{(float)ctr[0], (float)ctr[1], (float)ctr[2], -(Rf * Rf)});
+        }
+        while (cur.size() % 4 != 0) cur.push_back(never);
+        H.level_base[H.levels] = (uint32_t)H.nodes.size();
+        H.nodes.insert(H.nodes.end(), cur.begin(), cur.end());
+        cur.swap(par);
+        H.levels++;
+    }
+    while (cur.empty() || cur.size() % mrt::kGroup != 0) cur.push_back(never);
+    H.top.swap(cur);
 }
 
 // wait for everything this context has in flight (caller's stream and both side streams)
@@ -577,21 +648,20 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
         const float r = f32[w->spheres.radius_base_idx + i];
         recs[(size_t)i] = mrt::SphereRec{ctr[0], ctr[1], ctr[2], -(r * r)};
     }
-    // sweep records: bounding spheres of clusters of spatially close spheres
-    std::vector<mrt::SphereRec> clusters, members;
-    std::vector<uint32_t> member_index;
-    build_clusters(vec4 + 4 * w->spheres.center_base_idx, f32 + w->spheres.radius_base_idx, (uint32_t)n,
-                   c->cluster_factor, clusters, members, member_index);
-    const uint32_t n_padded = (uint32_t)clusters.size();
+    // bounding-sphere hierarchy over spatially close spheres; the sweep tests its top level
+    Hierarchy hier;
+    build_hierarchy(vec4 + 4 * w->spheres.center_base_idx, f32 + w->spheres.radius_base_idx, (uint32_t)n,
+                    c->cluster_factor, c->max_levels, c->top_target, hier);
+    const uint32_t n_padded = (uint32_t)hier.top.size();
     auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
         if (e != hipSuccess || !bytes) return e;
         return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     HIP_TRY(c, upload((void**)&c->d_spheres, recs.data(), recs.size() * sizeof(mrt::SphereRec)));
-    HIP_TRY(c, upload((void**)&c->d_clusters, clusters.data(), clusters.size() * sizeof(mrt::SphereRec)));
-    HIP_TRY(c, upload((void**)&c->d_members, members.data(), members.size() * sizeof(mrt::SphereRec)));
-    HIP_TRY(c, upload((void**)&c->d_member_index, member_index.data(), member_index.size() * sizeof(uint32_t)));
+    HIP_TRY(c, upload((void**)&c->d_clusters, hier.top.data(), hier.top.size() * sizeof(mrt::SphereRec)));
+    HIP_TRY(c, upload((void**)&c->d_nodes, hier.nodes.data(), hier.nodes.size() * sizeof(mrt::SphereRec)));
+    HIP_TRY(c, upload((void**)&c->d_member_index, hier.member_index.data(), hier.member_index.size() * sizeof(uint32_t)));
     HIP_TRY(c, upload((void**)&c->d_vec4, vec4, n_vec4 * 4 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
@@ -600,6 +670,8 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     c->world = *w;
     c->n_spheres = (uint32_t)n;
     c->n_padded = n_padded;
+    c->levels = hier.levels; c->n_nodes = (uint32_t)hier.nodes.size(); c->n_members = hier.n_members;
+    for (uint32_t k = 0; k < mrt::kMaxLevels; k++) c->level_base[k] = hier.level_base[k];
     c->have_world = true;
     return MRT_OK;
 }
@@ -686,9 +758,12 @@ int mrt_redraw(mrt_ctx* c) {
     p.n_spheres = c->n_spheres;
     p.n_padded = c->n_padded;
     { const uint32_t ch = (c->n_padded + mrt::kChunk - 1) / mrt::kChunk; p.mask_chunks = ch < 16u ? ch : 16u; }
+    p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
+    p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records
+    for (uint32_t k = 0; k < mrt::kMaxLevels; k++) p.level_base[k] = c->level_base[k];
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.cus = c->cus;
-    p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.members = c->d_members; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
+    p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
     p.seeds = c->d_seeds;
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
     p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
@@ -772,6 +847,13 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
 int mrt_debug_set_cluster_factor(mrt_ctx* c, float factor) {
     if (!c || !(factor >= 0.0f)) return MRT_ERR_INVALID_ARG;
     c->cluster_factor = factor;
+    return MRT_OK;
+}
+
+int mrt_debug_set_hierarchy(mrt_ctx* c, uint32_t max_levels, uint32_t top_target) {
+    if (!c || max_levels < 1 || max_levels > mrt::kMaxLevels || top_target < 1) return MRT_ERR_INVALID_ARG;
+    c->max_levels = max_levels;
+    c->top_target = top_target;
     return MRT_OK;
 }
 

@@ -209,11 +209,12 @@ constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 
 
 // The cooperative walk: candidates found by the sweep become wave-wide work items
 // (owner lane, node) in small LDS queues; every round 64 lanes take 64 items, whoever owns them.
-//   queue kLevels : (owner, cluster)  written by the owners from their sweep masks
-//   queue 0       : (owner, member)   members whose discriminant is >= 0, waiting for the root tests
-constexpr int kLevels = 1;                // cooperative levels above the member spheres
-constexpr uint32_t kGenCap = 576;         // capacity of the top queue
-constexpr uint32_t kQueueCap = 320;       // lower queues: < 64 left over + 4 x 64 pushed by one round
+// The bounding spheres form a 4-ary hierarchy of P.levels levels above the member spheres (level 0);
+// the sweep tests the top level, the walk descends:
+//   queue P.levels : (owner, top node)   written by the owners from their sweep masks
+//   queue k        : (owner, level-k node) whose bound the owner's ray may touch, 1 <= k < P.levels
+//   queue 0        : (owner, member)     members whose discriminant is >= 0, waiting for the root tests
+constexpr uint32_t kQueueCap = 320;       // < 64 left over + 4 x 64 pushed by one round (top queue: P.gen_cap)
 constexpr unsigned long long kNoHitKey = 0x461C4000FFFFFFFFull;   // (bits(1e4f) << 32) | -1
 
 template <bool SMALL> struct Ent;
@@ -224,9 +225,11 @@ template <> struct Ent<false> { typedef uint32_t type; static constexpr uint32_t
 __host__ __device__ constexpr uint32_t lds_off_rays() { return 0u; }                   // 64 x {ox,oy,oz,dx | dy,dz, u64 hit slot}
 __host__ __device__ constexpr uint32_t lds_off_ring() { return 2048u; }                // kRingCap x u32
 __host__ __device__ constexpr uint32_t lds_off_queues() { return 2048u + 512u; }
-__host__ __device__ constexpr uint32_t lds_queue_bytes(bool small) { return (kLevels * kQueueCap + kGenCap) * (small ? 2u : 4u); }
-__host__ __device__ constexpr uint32_t lds_off_masks(bool small) { return lds_off_queues() + lds_queue_bytes(small); }
-__host__ __device__ constexpr uint32_t lds_wave_bytes(bool small, uint32_t mask_chunks) { return lds_off_masks(small) + mask_chunks * 128u; }
+__host__ __device__ constexpr uint32_t lds_queue_bytes(bool small, uint32_t levels, uint32_t gen_cap) { return (levels * kQueueCap + gen_cap) * (small ? 2u : 4u); }
+__host__ __device__ constexpr uint32_t lds_off_masks(bool small, uint32_t levels, uint32_t gen_cap) { return lds_off_queues() + lds_queue_bytes(small, levels, gen_cap); }
+__host__ __device__ constexpr uint32_t lds_wave_bytes(bool small, uint32_t levels, uint32_t gen_cap, uint32_t mask_chunks) {
+    return lds_off_masks(small, levels, gen_cap) + mask_chunks * 128u;
+}
 
 // inclusive prefix sum over the 64 lanes of a wave (all lanes active)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
@@ -284,26 +287,30 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
     constexpr uint32_t kIdBits = Ent<SMALL>::id_bits;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t nodes_bytes = SMALL ? P.n_padded * kClusterK * (uint32_t)sizeof(SphereRec) : 0u;
-    unsigned char* const wlds = lds_raw + nodes_bytes + wave * lds_wave_bytes(SMALL, P.mask_chunks);
+    // small scenes always have one level (api.cpp): the queue bookkeeping below folds to two queues
+    constexpr int kLvMax = SMALL ? 1 : (int)kMaxLevels;
+    const uint32_t levels = SMALL ? 1u : P.levels;
+    const uint32_t nodes_bytes = SMALL ? P.n_nodes * (uint32_t)sizeof(SphereRec) : 0u;
+    unsigned char* const wlds = lds_raw + nodes_bytes + wave * lds_wave_bytes(SMALL, levels, P.gen_cap, P.mask_chunks);
     // lane l's 32 bytes: (ox,oy,oz,dx) (dy,dz) and the u64 slot its closest hit is min-ed into
     float4* const rays = reinterpret_cast<float4*>(wlds + lds_off_rays());
     unsigned long long* const best_slots = reinterpret_cast<unsigned long long*>(wlds + lds_off_rays()) + 3;   // slot of lane l at [4*l]
     uint32_t* const ring = reinterpret_cast<uint32_t*>(wlds + lds_off_ring());     // FIFO of waiting pixels: tile << 6 | lane-in-tile
     entry_t* const queues = reinterpret_cast<entry_t*>(wlds + lds_off_queues());   // queue k at k * kQueueCap
-    uint16_t* const masks = reinterpret_cast<uint16_t*>(wlds + lds_off_masks(SMALL)) + lane;   // chunk c at masks[c*64]
+    uint16_t* const masks = reinterpret_cast<uint16_t*>(wlds + lds_off_masks(SMALL, levels, P.gen_cap)) + lane;   // chunk c at masks[c*64]
     if (SMALL) {
         SphereRec* const dst = reinterpret_cast<SphereRec*>(lds_raw);
-        const uint32_t n_rec = P.n_padded * kClusterK;
-        for (uint32_t i = threadIdx.x; i < n_rec; i += 64u * kWavesPerGroup) dst[i] = P.members[i];
+        const uint32_t n_rec = P.n_nodes;
+        for (uint32_t i = threadIdx.x; i < n_rec; i += 64u * kWavesPerGroup) dst[i] = P.nodes[i];
         __syncthreads();
     }
 
     const uint32_t H = P.locals.shape[1];
     const uint32_t spp = PILOT ? P.pilot_spp : P.locals.samples_per_frame;
     const uint32_t n_padded = P.n_padded;
+    const uint32_t gen_cap = P.gen_cap;
     const SphereRec* __restrict__ spheres = P.spheres;
-    const SphereRec* members = SMALL ? reinterpret_cast<const SphereRec*>(lds_raw) : P.members;
+    const SphereRec* nodes = SMALL ? reinterpret_cast<const SphereRec*>(lds_raw) : P.nodes;   // levels 0 .. levels-1
     const uint32_t* __restrict__ member_index = P.member_index;
     const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.clusters;
     const float pixel_side = 2.0f / (float)H;                 // fs_main :373
@@ -479,12 +486,13 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
             // The records are wave-uniform: they are fetched with scalar loads, 8 records (two
             // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
             // loads of group g+1, then run the 8 x 11 VALU ops of group g while they fly.
-            Sph8 ga, gb;
-            smem_load8(ga, sph_quads, 0u);
-            asm volatile("" : "=s"(gb.lo), "=s"(gb.hi));   // defined (uniform) on every path to the final wait
             uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
             for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
                 const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
+                // the 64 record SGPRs are live only during the block's sweep, not during its walk
+                Sph8 ga, gb;
+                smem_load8(ga, sph_quads, blk);
+                asm volatile("" : "=s"(gb.lo), "=s"(gb.hi));   // defined (uniform) on every path to the block's final wait
                 uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
                 uint32_t rem = 0;                                       // this lane's candidate clusters in the block
                 uint32_t c = 0;
@@ -501,6 +509,9 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                     nz |= (m < 1u ? m : 1u) << c;
                     rem += (uint32_t)__builtin_popcount(m);
                 }
+                // the last prefetch is never consumed, but its destination SGPRs must stay reserved
+                // until it has landed
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi), "+s"(gb.lo), "+s"(gb.hi));
                 MRT_STAMP(1);
                 if (!usable) { nz = 0; rem = 0; }         // idle lanes; "weird" lanes take the literal loop below
                 lds_order();
@@ -509,22 +520,25 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                 uint32_t wm = 0, wfirst = 0;              // owner side: the chunk mask being unpacked, its first cluster id
                 uint32_t incl = wave_incl_scan(rem);
                 uint32_t total_rem = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                uint32_t qn[kLevels + 1];
+                uint32_t qn[kLvMax + 1];
 #pragma unroll
-                for (int lv = 0; lv <= kLevels; lv++) qn[lv] = 0u;
+                for (int lv = 0; lv <= kLvMax; lv++) qn[lv] = 0u;
                 for (;;) {
                     // a full round at the deepest level that has one; else refill the top queue; else
                     // a partial round at the highest level that has anything
                     int k = -1;
 #pragma unroll
-                    for (int lv = 0; lv <= kLevels; lv++) if (k < 0 && qn[lv] >= 64u) k = lv;
+                    for (int lv = 0; lv <= kLvMax; lv++) if (k < 0 && qn[lv] >= 64u) k = lv;
                     if (k < 0) {
                         if (total_rem != 0u) {
                             // owners unpack their masks into (owner, cluster) items at their scanned positions
                             const uint32_t excl = incl - rem;
-                            const uint32_t room = kGenCap - qn[kLevels];
+                            uint32_t n_top = 0;
+#pragma unroll
+                            for (int lv = 1; lv <= kLvMax; lv++) n_top = ((int)levels == lv) ? qn[lv] : n_top;
+                            const uint32_t room = gen_cap - n_top;
                             const uint32_t n_new = total_rem < room ? total_rem : room;
-                            entry_t* const dst = queues + kLevels * kQueueCap + qn[kLevels];
+                            entry_t* const dst = queues + levels * kQueueCap + n_top;
                             uint32_t p = excl;
                             while ((nz | wm) != 0u && p < n_new) {
                                 if (wm == 0u) {
@@ -539,7 +553,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                                 p++;
                             }
                             rem -= p - excl;
-                            qn[kLevels] += n_new;
+#pragma unroll
+                            for (int lv = 1; lv <= kLvMax; lv++) if ((int)levels == lv) qn[lv] += n_new;
                             total_rem -= n_new;
                             if (total_rem != 0u) incl = wave_incl_scan(rem);
                             lds_order();
@@ -547,12 +562,12 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                             continue;
                         }
 #pragma unroll
-                        for (int lv = kLevels; lv >= 0; lv--) if (k < 0 && qn[lv] != 0u) k = lv;
+                        for (int lv = kLvMax; lv >= 0; lv--) if (k < 0 && qn[lv] != 0u) k = lv;
                         if (k < 0) break;
                     }
                     uint32_t n = 0;
 #pragma unroll
-                    for (int lv = 0; lv <= kLevels; lv++) n = (k == lv) ? qn[lv] : n;
+                    for (int lv = 0; lv <= kLvMax; lv++) n = (k == lv) ? qn[lv] : n;
                     const uint32_t take = n < 64u ? n : 64u, start = n - take;
                     const bool act = lane < take;
                     const entry_t* const src = queues + (uint32_t)k * kQueueCap;
@@ -563,11 +578,19 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                     const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r0.w, r1.x, r1.y);
                     const float ra = dot3(rd, rd);                      // the owner's `a`, same expression
                     if (k != 0) {
-                        // node round: the reference's discriminant (shader.wgsl:274-282) for the 4 members of
-                        // each item's cluster; members with disc >= 0 become (owner, member) items
-                        // read q takes member (q + node/4) % 4, so that the 64 lanes of one read spread
-                        // over all 16 LDS slots (4 banks each) instead of the 4 that member q alone maps to
-                        const SphereRec* const ch = members + 4u * node;
+                        // node round, 4 children per item.  k == 1: the reference's discriminant (shader.wgsl:274-282)
+                        // for the cluster's members; members with disc >= 0 become (owner, member) items.
+                        // k >= 2: the sweep's conservative test on the child bounds (the same expression with
+                        // the direction stretched and a = 1, bit for bit test1()); passing children become items.
+                        // Read q takes child (q + node/4) % 4, so that the 64 lanes of one read spread
+                        // over all 16 LDS slots (4 banks each) instead of the 4 that child q alone maps to.
+                        const bool inner = kLvMax >= 2 && k >= 2;
+                        const float sc = inner ? 1.00003f : 1.0f, ra_eff = inner ? 1.0f : ra;
+                        const V3 re = v3(rd.x * sc, rd.y * sc, rd.z * sc);
+                        uint32_t cbase = 0;                 // first record of the children's level
+#pragma unroll
+                        for (int lv = 1; lv < kLvMax; lv++) cbase = (k - 1 == lv) ? P.level_base[lv] : cbase;
+                        const SphereRec* const ch = nodes + cbase + 4u * node;
                         const uint32_t rot = node >> 2;
                         bool h[4];
                         {
@@ -575,30 +598,31 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
                                 const float ocx = ro.x - sr[q].cx, ocy = ro.y - sr[q].cy, ocz = ro.z - sr[q].cz;
-                                const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
+                                const float bq = __builtin_fmaf(ocz, re.z, __builtin_fmaf(ocy, re.y, ocx * re.x));
                                 const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sr[q].neg_r2)));
-                                const float disc = __builtin_fmaf(bq, bq, -(ra * cq));
-                                h[q] = act && !(disc < 0.0f);
+                                const float disc = __builtin_fmaf(bq, bq, -(ra_eff * cq));
+                                h[q] = !(disc < 0.0f);
                             }
                         }
                         uint32_t dn = 0;
 #pragma unroll
-                        for (int lv = 0; lv < kLevels; lv++) dn = (k - 1 == lv) ? qn[lv] : dn;
+                        for (int lv = 0; lv < kLvMax; lv++) dn = (k - 1 == lv) ? qn[lv] : dn;
                         entry_t* const dst = queues + (uint32_t)(k - 1) * kQueueCap + dn;
                         const uint32_t e0 = (owner << kIdBits) | (4u * node);
                         uint32_t pushed = 0;
+                        const unsigned long long act_mask = take >= 64u ? ~0ull : ((1ull << take) - 1ull);
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(h[q]);
-                            if (h[q]) dst[pushed + rank_in(mk)] = (entry_t)(e0 + ((rot + (uint32_t)q) & 3u));
+                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(h[q]) & act_mask;
+                            if (h[q] && act) dst[pushed + rank_in(mk)] = (entry_t)(e0 + ((rot + (uint32_t)q) & 3u));
                             pushed += (uint32_t)__popcll(mk);
                         }
 #pragma unroll
-                        for (int lv = 0; lv <= kLevels; lv++) {
+                        for (int lv = 0; lv <= kLvMax; lv++) {
                             if (k == lv) qn[lv] = start;
                             if (k - 1 == lv) qn[lv] += pushed;
                         }
-                        if (COUNT) mtests += kClusterK * take;
+                        if (COUNT && k == 1) mtests += kClusterK * take;
 #ifdef MRT_STAMPS
                         rounds_a_++; items_a_ += take;
 #endif
@@ -611,7 +635,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                         // (t, index) over spheres with a root in [0.001, 1e4) -- what the reference's
                         // index-order scan with `t_sup <= t` (:291-296) ends with (`near` is tried first,
                         // `far` only if `near` is out of range: near >= t_sup implies far >= t_sup).
-                        const SphereRec sm = members[node];
+                        const SphereRec sm = nodes[node];
                         const uint32_t sidx = member_index[node];
                         const float ocx = ro.x - sm.cx, ocy = ro.y - sm.cy, ocz = ro.z - sm.cz;
                         const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
@@ -637,9 +661,6 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                     }
                 }
             }
-            // the last prefetches are never consumed, but their destination SGPRs must stay
-            // reserved until they have landed
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi), "+s"(gb.lo), "+s"(gb.hi));
             if (trace) {
                 if (weird) {
                     for (uint32_t idx = 0; idx < P.n_spheres; idx++)
@@ -835,9 +856,9 @@ __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64
 }  // namespace
 
 // SMALL scenes (every node id < 1024): member records live in LDS and work items are u16
-static bool scene_is_small(const KParams& p) { return p.n_padded * kClusterK <= 1024u; }
+static bool scene_is_small(const KParams& p) { return p.n_members <= 1024u; }
 static uint32_t group_lds_bytes(const KParams& p, bool small) {
-    return (small ? p.n_padded * kClusterK * (uint32_t)sizeof(SphereRec) : 0u) + kWavesPerGroup * lds_wave_bytes(small, p.mask_chunks);
+    return (small ? p.n_nodes * (uint32_t)sizeof(SphereRec) : 0u) + kWavesPerGroup * lds_wave_bytes(small, p.levels, p.gen_cap, p.mask_chunks);
 }
 
 // queue reset + the persistent render waves (pilot: + its cost-only finalize) on `stream`

@@ -12,6 +12,7 @@ constexpr uint32_t kChunk = 16;          // spheres per chunk of the discriminan
 constexpr uint32_t kGroup = 8;           // records per scalar-load group; the sweep list is padded to this
 constexpr uint32_t kClusterK = 4;        // spheres per sweep record (cluster)
 constexpr uint32_t kMaxSpheres = 1u << 20;
+constexpr uint32_t kMaxLevels = 4;       // levels of bounding spheres above the member spheres
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
 // the host from the reference's SoA arrays (centres: vec4_f32_data, radii: f32_data;
@@ -31,13 +32,17 @@ struct KParams {
     uint32_t shard_rank, shard_world;
     uint32_t cus;               // compute units of the device (host-side launch sizing only)
     const SphereRec* spheres;   // n_spheres records in the reference's order (exact tests)
-    // The discriminant sweep runs over CLUSTER records: the bounding sphere (cx,cy,cz,-R^2) of up to
-    // kClusterK spatially close spheres, n_padded of them (multiple of kGroup, padded with never-hit
-    // entries).  Cluster c stands for members[c*kClusterK .. +kClusterK) (short clusters are padded
-    // with never-hit records); member_index[] is each member's index in the reference's sphere order.
+    // Bounding-sphere hierarchy (api.cpp build_hierarchy): level 0 = the member spheres in cluster order
+    // (4 per cluster, short clusters padded with never-hit records), level 1 = the clusters' bounds
+    // (cx,cy,cz,-R^2), level k+1 = bounds of 4 consecutive level-k nodes; node j of level k has the
+    // children 4j..4j+3 of level k-1.  The sweep runs over the TOP level (`levels`): `clusters`, n_padded
+    // records (multiple of kGroup, padded with never-hit entries).  `nodes` holds levels 0..levels-1,
+    // level k at level_base[k]; member_index[] is each member's index in the reference's sphere order.
     const SphereRec* clusters;
-    const SphereRec* members;
+    const SphereRec* nodes;
     const uint32_t* member_index;
+    uint32_t levels, n_nodes, n_members, gen_cap;
+    uint32_t level_base[kMaxLevels];
     const float* vec4_data;     // r_vec4_f32_data (shader.wgsl:189-190), 4 floats per texel
     const float* f32_data;      // r_f32_data
     const int32_t* i32_data;    // r_i32_data

@@ -15,6 +15,10 @@ def run(scene, w, h, spp, depth=50, frames=2, shard=None):
             from myraytracer_amd import _lib
             a_ = [int(x) for x in sched.split(",")]
             assert _lib.load().mrt_debug_set_schedule(st._ctx, a_[0], a_[1]) == 0
+        if os.environ.get("MRT_HIER"):        # "max_levels,top_target"
+            from myraytracer_amd import _lib
+            h_ = [int(x) for x in os.environ["MRT_HIER"].split(",")]
+            assert _lib.load().mrt_debug_set_hierarchy(st._ctx, h_[0], h_[1]) == 0
         if os.environ.get("MRT_CLUSTER"):
             from myraytracer_amd import _lib
             _lib.load().mrt_debug_set_cluster_factor(st._ctx, float(os.environ["MRT_CLUSTER"]))

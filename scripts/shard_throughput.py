@@ -7,6 +7,10 @@ w, h, spp, rank, world = (int(x) for x in sys.argv[1:6])
 K = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 sp, cam = M.scene_cover(1, True)
 with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 1 else None) as st:
+    if os.environ.get("MRT_HIER"):        # "max_levels,top_target"
+        from myraytracer_amd import _lib
+        h_ = [int(x) for x in os.environ["MRT_HIER"].split(",")]
+        assert _lib.load().mrt_debug_set_hierarchy(st._ctx, h_[0], h_[1]) == 0
     if os.environ.get("MRT_CLUSTER"):
         from myraytracer_amd import _lib
         _lib.load().mrt_debug_set_cluster_factor(st._ctx, float(os.environ["MRT_CLUSTER"]))
