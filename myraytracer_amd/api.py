@@ -327,6 +327,10 @@ class State:
         self._check(self._L.mrt_kernel_ms_history(self._ctx, buf, n, C.byref(got)), "mrt_kernel_ms_history")
         return [float(buf[i]) for i in range(got.value)]
 
+    def debug_set_hierarchy(self, max_levels: int, top_target: int):
+        """Tuning / test hook: depth rule of the bounding-sphere hierarchy built by the next set_world()."""
+        self._check(self._L.mrt_debug_set_hierarchy(self._ctx, max_levels, top_target), "mrt_debug_set_hierarchy")
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._check(self._L.mrt_last_kernel_ms(self._ctx, C.byref(ms)), "mrt_last_kernel_ms")

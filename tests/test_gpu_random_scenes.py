@@ -87,3 +87,41 @@ def test_large_coordinates_keep_cluster_bounds_conservative(mrt, oracle):
     ref = oracle_render(oracle, sc, cam, 80, 60, 6, 10, 3)
     got, _, _ = gpu_render(mrt, sc, cam, 80, 60, 6, 10, 3)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+
+
+@pytest.mark.parametrize("n", [1100, 2600])
+def test_hierarchy_depth_does_not_change_pixels(mrt, oracle, n):
+    """Scenes beyond 1,024 members walk a hierarchy of bounding spheres (u32 work items, nodes in HBM);
+    its depth and the size of the swept top level are tuning knobs and must never show in the image."""
+    rng = np.random.default_rng(n)
+    sc = _random_scene(mrt, rng, n)
+    cam = mrt.Camera(1, (5.0, 3.0, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, 0.3, 7.0)
+    cnt = oracle.Counters()
+    ref = oracle_render(oracle, sc, cam, 56, 32, 3, 9, 77, counters=cnt)
+    for max_levels, top_target in [(1, 64), (2, 64), (3, 8), (4, 1), (4, 64)]:
+        with mrt.State(mrt.Args(56, 32, 3, 9, 1.0), seed=77) as st:
+            st.debug_set_hierarchy(max_levels, top_target)
+            st.set_world(sc)
+            st.set_camera(cam)
+            st.render(1)
+            got, c = st.read_framebuffer(), st.read_counters()
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        assert same.all(), f"hierarchy {max_levels},{top_target}: " + mismatch_report(got, ref)
+        assert c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
+
+
+def test_every_queue_overflows_in_a_deep_hierarchy(mrt, oracle):
+    """1,100 concentric shells: every ray is a candidate for every node of every level, so the top queue is
+    refilled in several passes and every lower queue runs full."""
+    n = 1100
+    sc = np.zeros(n, mrt.SPHERE_DTYPE)
+    for i in range(n):
+        sc[i] = ((0, 0, -3), 0.5 + 0.0005 * (i % 550), 1 + (i % 3), (0.8, 0.7, 0.6), 0.2 if i % 3 == 1 else 1.5)
+    ref = oracle_render(oracle, sc, None, 40, 24, 2, 6, 9)
+    for max_levels, top_target in [(1, 64), (4, 1)]:
+        with mrt.State(mrt.Args(40, 24, 2, 6, 1.0), seed=9) as st:
+            st.debug_set_hierarchy(max_levels, top_target)
+            st.set_world(sc)
+            st.render(1)
+            got = st.read_framebuffer()
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"hierarchy {max_levels},{top_target}: " + mismatch_report(got, ref)
