@@ -205,49 +205,30 @@ uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
 
 bool finite_in_range(float v, float lim) { return std::isfinite(v) && std::fabs(v) <= lim; }
 
-// Sweep records.  The kernel's discriminant sweep does not need the spheres themselves, only a
-// conservative "could this ray touch it" test, so spatially close spheres are tested in CLUSTERS of up
-// to kClusterK through one bounding sphere (a quarter of the sweep) and the per-sphere discriminants
-// are evaluated only for the members of the few clusters that pass.  Spheres are ordered along a
-// Morton curve and consecutive ones are grouped while the enclosing sphere stays within `factor`
-// times the largest member radius; spheres much larger than the median (a ground sphere) stay alone.
-// R is 6 % above the enclosing radius: part of the conservativeness argument in DESIGN.md §4.
-// Clusters are padded to kClusterK members and the list to a multiple of kGroup with never-hit
-// records (-r^2 = +inf gives a discriminant of -inf).
+// Clusters.  The kernel's sweep does not need the spheres themselves, only a conservative "could this
+// ray touch it" test, so spatially close spheres are tested in CLUSTERS of up to kClusterK through one
+// bounding sphere and the per-sphere discriminants are evaluated only for the members of the few clusters
+// that pass.  A ray's expected number of candidates is proportional to the sum of the bounds' cross
+// sections, so the grouping minimises sum(R^2): spheres are split kd-tree fashion (widest axis of the
+// centres, at a multiple of kClusterK near the median) down to groups of <= 8, and such a group is cut
+// into 4 + rest by trying every choice.  Spheres far larger than the median (a ground sphere) stay alone;
+// factor == 0 (diagnostic) keeps every sphere alone.  Consecutive clusters are kd siblings, which is what
+// the upper levels (build_hierarchy) group.  R is 6 % above the enclosing radius measured from the
+// f32-rounded centre: part of the conservativeness argument in DESIGN.md §4.  Clusters are padded to
+// kClusterK members and the list to a multiple of kGroup with never-hit records (-r^2 = +inf gives a
+// discriminant of -inf).
 void build_clusters(const float* centers4, const float* radii, uint32_t n, float factor,
                     std::vector<mrt::SphereRec>& clusters, std::vector<mrt::SphereRec>& members,
                     std::vector<uint32_t>& member_index) {
     clusters.clear(); members.clear(); member_index.clear();
     const mrt::SphereRec never{0.0f, 0.0f, 0.0f, INFINITY};
-    std::vector<uint32_t> order(n);
     std::vector<double> rs(n);
-    for (uint32_t i = 0; i < n; i++) { order[i] = i; rs[i] = std::fabs((double)radii[i]); }
+    for (uint32_t i = 0; i < n; i++) rs[i] = std::fabs((double)radii[i]);
     double big = 1e300;
     if (n > 1) {
         std::vector<double> sorted = rs;
         std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
         big = 8.0 * sorted[n / 2];
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        for (uint32_t i = 0; i < n; i++) {
-            if (rs[i] > big) continue;
-            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)centers4[4 * i + k]); hi[k] = std::max(hi[k], (double)centers4[4 * i + k]); }
-        }
-        std::vector<uint64_t> codes(n);
-        for (uint32_t i = 0; i < n; i++) {
-            if (rs[i] > big) { codes[i] = ~0ull; continue; }  // large spheres sort to the end
-            uint32_t q[3];
-            const double ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));   // one scale for all axes
-            for (int k = 0; k < 3; k++) {
-                double t = ext > 0 ? ((double)centers4[4 * i + k] - lo[k]) / ext : 0.0;
-                t = t < 0 ? 0 : (t > 1 ? 1 : t);
-                q[k] = (uint32_t)(t * 1023.0);
-            }
-            uint64_t code = 0;
-            for (int bit = 9; bit >= 0; bit--)
-                for (int k = 0; k < 3; k++) code = (code << 1) | ((q[k] >> bit) & 1u);
-            codes[i] = code;
-        }
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] < codes[b]; });
     }
     // enclosing sphere of a set: centre of the members' common bounding box, R = max(|c_m - centre| + r_m)
     auto enclose = [&](const uint32_t* idx, uint32_t cnt, double ctr[3]) -> double {
@@ -267,36 +248,72 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
         }
         return R;
     };
-    for (uint32_t k = 0; k < n;) {
-        uint32_t idx[mrt::kClusterK];
-        uint32_t cnt = 1;
-        idx[0] = order[k];
-        double ctr[3];
-        double R = enclose(idx, 1, ctr);
-        double rmax = rs[idx[0]];
-        while (cnt < mrt::kClusterK && k + cnt < n && rs[idx[0]] <= big && rs[order[k + cnt]] <= big) {
-            idx[cnt] = order[k + cnt];
-            double c2[3];
-            const double R2 = enclose(idx, cnt + 1, c2);
-            const double rm2 = std::max(rmax, rs[idx[cnt]]);
-            if (R2 > (double)factor * rm2) break;
-            R = R2; rmax = rm2; cnt++;
-            for (int q = 0; q < 3; q++) ctr[q] = c2[q];
+    std::vector<std::vector<uint32_t>> groups;
+    std::vector<uint32_t> pool;                      // spheres that may share a cluster
+    std::vector<uint32_t> alone;
+    for (uint32_t i = 0; i < n; i++) (factor > 0.0f && rs[i] <= big ? pool : alone).push_back(i);
+    // iterative kd split of pool[lo, hi)
+    std::vector<std::pair<uint32_t, uint32_t>> stack;
+    if (!pool.empty()) stack.push_back({0u, (uint32_t)pool.size()});
+    std::vector<std::pair<uint32_t, uint32_t>> leaves;      // in kd order
+    while (!stack.empty()) {
+        const auto [lo, hi] = stack.back();
+        stack.pop_back();
+        const uint32_t m = hi - lo;
+        if (m <= 2 * mrt::kClusterK) { leaves.push_back({lo, hi}); continue; }
+        double bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
+        for (uint32_t q = lo; q < hi; q++)
+            for (int k = 0; k < 3; k++) {
+                bl[k] = std::min(bl[k], (double)centers4[4 * pool[q] + k]);
+                bh[k] = std::max(bh[k], (double)centers4[4 * pool[q] + k]);
+            }
+        int ax = 0;
+        for (int k = 1; k < 3; k++) if (bh[k] - bl[k] > bh[ax] - bl[ax]) ax = k;
+        std::stable_sort(pool.begin() + lo, pool.begin() + hi, [&](uint32_t x, uint32_t y) {
+            const float cx = centers4[4 * x + ax], cy = centers4[4 * y + ax];
+            return cx < cy || (cx == cy && x < y);
+        });
+        uint32_t h = (m / 2 + mrt::kClusterK - 1) / mrt::kClusterK * mrt::kClusterK;
+        if (h >= m) h = m - mrt::kClusterK;
+        stack.push_back({lo + h, hi});              // popped second: keeps the leaves in left-to-right order
+        stack.push_back({lo, lo + h});
+    }
+    for (const auto& [lo, hi] : leaves) {
+        const uint32_t m = hi - lo;
+        if (m <= mrt::kClusterK) { groups.emplace_back(pool.begin() + lo, pool.begin() + hi); continue; }
+        // 5..8 spheres: the first one plus the 3 others that minimise R_A^2 + R_B^2
+        uint32_t bestmask = 0;
+        double best = 1e300;
+        for (uint32_t mask = 0; mask < (1u << m); mask++) {
+            if (!(mask & 1u) || __builtin_popcount(mask) != (int)mrt::kClusterK) continue;
+            uint32_t A[8], B[8], na = 0, nb = 0;
+            for (uint32_t q = 0; q < m; q++) ((mask >> q) & 1u ? A[na++] : B[nb++]) = pool[lo + q];
+            double ctr[3];
+            const double ra = enclose(A, na, ctr), rb = enclose(B, nb, ctr);
+            if (ra * ra + rb * rb < best) { best = ra * ra + rb * rb; bestmask = mask; }
         }
+        std::vector<uint32_t> A, B;
+        for (uint32_t q = 0; q < m; q++) ((bestmask >> q) & 1u ? A : B).push_back(pool[lo + q]);
+        groups.push_back(A);
+        groups.push_back(B);
+    }
+    for (uint32_t i : alone) groups.push_back({i});
+    for (auto& g : groups) {
+        std::sort(g.begin(), g.end());
+        double ctr[3];
+        const double R = enclose(g.data(), (uint32_t)g.size(), ctr);
         const float Rf = (float)(R * 1.06) + 1e-30f;     // rounding R to f32 moves it by 6e-8 R, the 6 % is for the proof
         clusters.push_back(mrt::SphereRec{(float)ctr[0], (float)ctr[1], (float)ctr[2], -(Rf * Rf)});
-        std::sort(idx, idx + cnt);
         for (uint32_t m = 0; m < mrt::kClusterK; m++) {
-            if (m < cnt) {
-                const float r = radii[idx[m]];
-                members.push_back(mrt::SphereRec{centers4[4 * idx[m]], centers4[4 * idx[m] + 1], centers4[4 * idx[m] + 2], -(r * r)});
-                member_index.push_back(idx[m]);
+            if (m < g.size()) {
+                const float r = radii[g[m]];
+                members.push_back(mrt::SphereRec{centers4[4 * g[m]], centers4[4 * g[m] + 1], centers4[4 * g[m] + 2], -(r * r)});
+                member_index.push_back(g[m]);
             } else {
                 members.push_back(never);
                 member_index.push_back(0u);
             }
         }
-        k += cnt;
     }
     while (clusters.empty() || clusters.size() % mrt::kGroup != 0) {
         clusters.push_back(never);                                    // S = -inf: never a candidate
