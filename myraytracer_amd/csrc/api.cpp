@@ -52,6 +52,8 @@ struct mrt_ctx {
     uint32_t max_levels = mrt::kMaxLevels, top_target = 64;   // hierarchy depth rule (build_hierarchy)
     uint32_t levels = 1, n_nodes = 0, n_members = 0;
     uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
+    uint32_t n_direct = 0, direct_first = 0;
+    mrt::SphereRec direct[mrt::kMaxDirect] = {};
     float* d_vec4 = nullptr;
     float* d_f32 = nullptr;
     int32_t* d_i32 = nullptr;
@@ -212,15 +214,15 @@ bool finite_in_range(float v, float lim) { return std::isfinite(v) && std::fabs(
 // sections, so the grouping minimises sum(R^2): spheres are split kd-tree fashion (widest axis of the
 // centres, at a multiple of kClusterK near the median) down to groups of <= 8, and such a group is cut
 // into 4 + rest by trying every choice.  Spheres far larger than the median (a ground sphere) stay alone;
-// factor == 0 (diagnostic) keeps every sphere alone.  Consecutive clusters are kd siblings, which is what
+// factor == 0 (diagnostic) gives every sphere a cluster of its own.  Consecutive clusters are kd siblings, which is what
 // the upper levels (build_hierarchy) group.  R is 6 % above the enclosing radius measured from the
 // f32-rounded centre: part of the conservativeness argument in DESIGN.md §4.  Clusters are padded to
 // kClusterK members and the list to a multiple of kGroup with never-hit records (-r^2 = +inf gives a
 // discriminant of -inf).
 void build_clusters(const float* centers4, const float* radii, uint32_t n, float factor,
                     std::vector<mrt::SphereRec>& clusters, std::vector<mrt::SphereRec>& members,
-                    std::vector<uint32_t>& member_index) {
-    clusters.clear(); members.clear(); member_index.clear();
+                    std::vector<uint32_t>& member_index, std::vector<uint32_t>& direct) {
+    clusters.clear(); members.clear(); member_index.clear(); direct.clear();
     const mrt::SphereRec never{0.0f, 0.0f, 0.0f, INFINITY};
     std::vector<double> rs(n);
     for (uint32_t i = 0; i < n; i++) rs[i] = std::fabs((double)radii[i]);
@@ -297,7 +299,13 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
         groups.push_back(A);
         groups.push_back(B);
     }
-    for (uint32_t i : alone) groups.push_back({i});
+    // the largest of the big spheres are tested by every ray directly (KParams::direct); the others get a
+    // cluster of their own
+    std::stable_sort(alone.begin(), alone.end(), [&](uint32_t x, uint32_t y) { return rs[x] > rs[y]; });
+    for (uint32_t q = 0; q < alone.size(); q++) {
+        if (factor > 0.0f && q < mrt::kMaxDirect && rs[alone[q]] > big) direct.push_back(alone[q]);
+        else groups.push_back({alone[q]});
+    }
     for (auto& g : groups) {
         std::sort(g.begin(), g.end());
         double ctr[3];
@@ -331,22 +339,40 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
 struct Hierarchy {
     std::vector<mrt::SphereRec> top, nodes;
     std::vector<uint32_t> member_index;
-    uint32_t levels = 1, n_members = 0;
+    uint32_t levels = 1, n_members = 0;       // n_members: level 0 including the direct spheres
     uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
+    uint32_t n_direct = 0, direct_first = 0;
+    mrt::SphereRec direct[mrt::kMaxDirect] = {};
 };
 
 void build_hierarchy(const float* centers4, const float* radii, uint32_t n, float factor, uint32_t max_levels,
                      uint32_t top_target, Hierarchy& H) {
     const mrt::SphereRec never{0.0f, 0.0f, 0.0f, INFINITY};
     std::vector<mrt::SphereRec> members, cur;
-    build_clusters(centers4, radii, n, factor, cur, members, H.member_index);
-    H.n_members = (uint32_t)members.size();
+    std::vector<uint32_t> direct;
+    build_clusters(centers4, radii, n, factor, cur, members, H.member_index, direct);
     H.nodes = members;
+    // the direct spheres follow the clusters' members in level 0 (no cluster, no bound above them)
+    H.n_direct = (uint32_t)direct.size();
+    H.direct_first = (uint32_t)members.size();
+    for (uint32_t j = 0; j < mrt::kClusterK; j++) {
+        mrt::SphereRec rec = never;
+        uint32_t idx = 0;
+        if (j < direct.size()) {
+            idx = direct[j];
+            const float r = radii[idx];
+            rec = mrt::SphereRec{centers4[4 * idx], centers4[4 * idx + 1], centers4[4 * idx + 2], -(r * r)};
+        }
+        H.direct[j] = rec;
+        if (!direct.empty()) { H.nodes.push_back(rec); H.member_index.push_back(idx); }
+    }
+    static_assert(mrt::kMaxDirect == mrt::kClusterK, "level 0 stays a multiple of kClusterK");
+    H.n_members = (uint32_t)H.nodes.size();
     H.levels = 1;
     H.level_base[0] = 0;
     // scenes whose members fit 10-bit ids (the kernel's SMALL variant) keep one level: with <= 256 clusters
     // the sweep is cheap and the bounds of 16 spheres are loose (C3: a ray touches 10 of 38 such bounds)
-    if (H.n_members <= 1024u) max_levels = 1;
+    if (H.n_members <= 1024u) max_levels = 1;      // (same test as scene_is_small() in kernels.hip)
     while (H.levels < max_levels && cur.size() > top_target) {
         const size_t span = (size_t)1 << (2 * (H.levels + 1));        // members under one node of the new level
         const size_t n_par = (cur.size() + 3) / 4;
@@ -689,6 +715,8 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     c->n_padded = n_padded;
     c->levels = hier.levels; c->n_nodes = (uint32_t)hier.nodes.size(); c->n_members = hier.n_members;
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) c->level_base[k] = hier.level_base[k];
+    c->n_direct = hier.n_direct; c->direct_first = hier.direct_first;
+    for (uint32_t k = 0; k < mrt::kMaxDirect; k++) c->direct[k] = hier.direct[k];
     c->have_world = true;
     return MRT_OK;
 }
@@ -778,6 +806,8 @@ int mrt_redraw(mrt_ctx* c) {
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
     p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) p.level_base[k] = c->level_base[k];
+    p.n_direct = c->n_direct; p.direct_first = c->direct_first;
+    for (uint32_t k = 0; k < mrt::kMaxDirect; k++) p.direct[k] = c->direct[k];
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.cus = c->cus;
     p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;

@@ -486,6 +486,26 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
             // The records are wave-uniform: they are fetched with scalar loads, 8 records (two
             // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
             // loads of group g+1, then run the 8 x 11 VALU ops of group g while they fly.
+            // The few spheres far larger than the rest (a ground sphere) are outside the hierarchy: every
+            // ray evaluates their discriminant (shader.wgsl:274-282) itself, record in SGPRs, and queues
+            // the ones with disc >= 0 for the root rounds like any other member.
+            uint32_t n_hits0 = 0;
+            {
+                const KArgPtr C = cold_args();
+                const uint32_t n_direct = C->n_direct;
+                for (uint32_t j = 0; j < n_direct; j++) {
+                    const float cx = C->direct[j].cx, cy = C->direct[j].cy, cz = C->direct[j].cz, nr2 = C->direct[j].neg_r2;
+                    const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+                    const float bq = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));
+                    const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, nr2)));
+                    const float disc = __builtin_fmaf(bq, bq, -(a * cq));
+                    const bool hq = usable && !(disc < 0.0f);
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(hq);
+                    if (hq) queues[n_hits0 + rank_in(mk)] = (entry_t)((lane << kIdBits) | (C->direct_first + j));
+                    n_hits0 += (uint32_t)__popcll(mk);
+                }
+                if (COUNT) mtests += (unsigned long long)n_direct * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(usable));
+            }
             uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
             for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
                 const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
@@ -523,6 +543,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                 uint32_t qn[kLvMax + 1];
 #pragma unroll
                 for (int lv = 0; lv <= kLvMax; lv++) qn[lv] = 0u;
+                qn[0] = n_hits0;            // (at most kMaxDirect x 64 <= the queue's capacity; root rounds come first)
+                n_hits0 = 0;
                 for (;;) {
                     // a full round at the deepest level that has one; else refill the top queue; else
                     // a partial round at the highest level that has anything

@@ -13,6 +13,7 @@ constexpr uint32_t kGroup = 8;           // records per scalar-load group; the s
 constexpr uint32_t kClusterK = 4;        // spheres per sweep record (cluster)
 constexpr uint32_t kMaxSpheres = 1u << 20;
 constexpr uint32_t kMaxLevels = 4;       // levels of bounding spheres above the member spheres
+constexpr uint32_t kMaxDirect = 4;       // very large spheres tested by every ray directly, outside the hierarchy
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
 // the host from the reference's SoA arrays (centres: vec4_f32_data, radii: f32_data;
@@ -43,6 +44,11 @@ struct KParams {
     const uint32_t* member_index;
     uint32_t levels, n_nodes, n_members, gen_cap;
     uint32_t level_base[kMaxLevels];
+    // Spheres far larger than the rest (a ground sphere) are candidates for nearly every ray: up to kMaxDirect
+    // of them stay out of the hierarchy and every ray evaluates their discriminant itself, from SGPRs.
+    // They are the members direct_first .. direct_first + n_direct - 1 of level 0.
+    uint32_t n_direct, direct_first;
+    SphereRec direct[kMaxDirect];
     const float* vec4_data;     // r_vec4_f32_data (shader.wgsl:189-190), 4 floats per texel
     const float* f32_data;      // r_f32_data
     const int32_t* i32_data;    // r_i32_data
