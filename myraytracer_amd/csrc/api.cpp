@@ -46,6 +46,7 @@ struct mrt_ctx {
     // device memory (all owned)
     mrt::SphereRec* d_spheres = nullptr;
     mrt::SphereRec* d_clusters = nullptr;  // bounding spheres the sweep tests (up to kClusterK spheres each)
+    float* d_shade = nullptr;              // 8 floats per sphere: centre, radius, material colour, fuzz | ior
     mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
     uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
     float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
@@ -140,11 +141,12 @@ void free_world(mrt_ctx* c) {
     if (c->d_spheres) (void)hipFree(c->d_spheres);
     if (c->d_clusters) (void)hipFree(c->d_clusters);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_shade) (void)hipFree(c->d_shade);
     if (c->d_member_index) (void)hipFree(c->d_member_index);
     if (c->d_vec4) (void)hipFree(c->d_vec4);
     if (c->d_f32) (void)hipFree(c->d_f32);
     if (c->d_i32) (void)hipFree(c->d_i32);
-    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
+    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_shade = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
     c->have_world = false;
 }
 
@@ -705,6 +707,26 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     HIP_TRY(c, upload((void**)&c->d_clusters, hier.top.data(), hier.top.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_nodes, hier.nodes.data(), hier.nodes.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_member_index, hier.member_index.data(), hier.member_index.size() * sizeof(uint32_t)));
+    // what shading a hit on sphere i reads, gathered per sphere (bit copies of the SoA entries)
+    std::vector<float> shade(8 * ((size_t)n ? (size_t)n : 1), 0.0f);
+    for (int64_t i = 0; i < n; i++) {
+        const float* ctr = vec4 + 4 * (w->spheres.center_base_idx + i);
+        float* sh = shade.data() + 8 * (size_t)i;
+        sh[0] = ctr[0]; sh[1] = ctr[1]; sh[2] = ctr[2];
+        sh[3] = f32[w->spheres.radius_base_idx + i];
+        const int32_t ty = i32[w->spheres.material_ty_base_idx + i];
+        const int32_t mi = i32[w->spheres.material_idx_base_idx + i];
+        sh[4] = sh[5] = sh[6] = 1.0f; sh[7] = 0.0f;
+        if (ty == MRT_LAMBERTIAN) {
+            std::memcpy(sh + 4, vec4 + 4 * (w->lambertians.albedo_base_idx + mi), 3 * sizeof(float));
+        } else if (ty == MRT_METAL) {
+            std::memcpy(sh + 4, vec4 + 4 * (w->metals.albedo_base_idx + mi), 3 * sizeof(float));
+            sh[7] = f32[w->metals.fuzz_base_idx + mi];
+        } else if (ty == MRT_DIELECTRIC) {
+            sh[7] = f32[w->dielectrics.ior_base_idx + mi];
+        }
+    }
+    HIP_TRY(c, upload((void**)&c->d_shade, shade.data(), shade.size() * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_vec4, vec4, n_vec4 * 4 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
@@ -810,7 +832,7 @@ int mrt_redraw(mrt_ctx* c) {
     for (uint32_t k = 0; k < mrt::kMaxDirect; k++) p.direct[k] = c->direct[k];
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.cus = c->cus;
-    p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
+    p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.shade = c->d_shade; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
     p.seeds = c->d_seeds;
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
     p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)

@@ -86,42 +86,6 @@ __device__ __forceinline__ V3 rng_unit_ball(Rng& r) {            // shader.wgsl:
     return v;
 }
 
-// ---- scene access (shader.wgsl:198-201, 218-226, 254-268) ----------------------------
-__device__ __forceinline__ V3 load_vec4_xyz(const float* vec4_data, int32_t idx) {
-    const float4 v = reinterpret_cast<const float4*>(vec4_data)[idx];
-    return v3(v.x, v.y, v.z);
-}
-
-// One exact sphere test for the sphere `idx`: shader.wgsl:274-296 with the hit record deferred
-// (only t and the index are kept; at/normal/material are rebuilt once per bounce from the winning
-// sphere, which gives the same values because they depend only on t).
-// Candidates do not arrive in index order (they come pair by pair), so the reference's tie rule --
-// the scan runs in index order and `t_sup <= t` rejects a later sphere at the same t, i.e. the
-// LOWEST index wins -- is applied explicitly: a root is accepted if it is closer than the best so
-// far, or equally close with a lower sphere index.  Either processing order ends at the
-// lexicographic minimum of (t, index) over all spheres with a root in [t_min, 1e4).
-__device__ __forceinline__ void exact_test(const SphereRec s, uint32_t idx, V3 o, V3 d, float a,
-                                           float& t_sup, int32_t& best) {
-    V3 oc = v3(o.x - s.cx, o.y - s.cy, o.z - s.cz);
-    float b = dot3(oc, d);
-    float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, s.neg_r2)));
-    float disc = __builtin_fmaf(b, b, -(a * c));
-    if (!(disc < 0.0f)) {                                        // :282
-        float d_sqrt = __builtin_sqrtf(disc);                    // :286
-        const float t_min = 0.001f;                              // :340
-        float t = (-b - d_sqrt) / a;                             // :290
-        bool ok = !(t < t_min) && (t < t_sup || (t == t_sup && (int32_t)idx < best));
-        if (!ok) {                                               // :291-293
-            t = (-b + d_sqrt) / a;
-            ok = !(t < t_min) && (t < t_sup || (t == t_sup && (int32_t)idx < best));
-        }
-        if (ok) {                                                // :294-296
-            t_sup = t;                                           // world_hit :322
-            best = (int32_t)idx;
-        }
-    }
-}
-
 // The reference's literal acceptance test, for the index-ordered loop over ALL spheres that rays
 // with a non-finite or non-unit direction take: NaN compares false, so a NaN root is accepted.
 __device__ __forceinline__ void literal_test(const SphereRec s, uint32_t idx, V3 o, V3 d, float a,
@@ -710,33 +674,40 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                     path_done = true;
                 } else {
                     // rest of sphere_hit for the winning sphere, shader.wgsl:298-309
+                    // (centre, radius) and (material colour, fuzz | ior) of sphere `best` come packed in two
+                    // 16-byte records built at upload from the reference's SoA arrays (sphere_load_* :254-268,
+                    // albedo / fuzz loads :205, :232-240): the same bits, one round trip instead of a chain of four.
                     const KArgPtr C = cold_args();
-                    const V3 center = load_vec4_xyz(C->vec4_data, C->world.spheres.center_base_idx + best);
-                    const float radius = C->f32_data[C->world.spheres.radius_base_idx + best];
+                    const float4 sh0 = reinterpret_cast<const float4*>(C->shade)[2 * best];
+                    const float4 sh1 = reinterpret_cast<const float4*>(C->shade)[2 * best + 1];
                     const int32_t m_ty = C->i32_data[C->world.spheres.material_ty_base_idx + best];
-                    const int32_t m_idx = C->i32_data[C->world.spheres.material_idx_base_idx + best];
+                    const V3 center = v3(sh0.x, sh0.y, sh0.z);
+                    const float radius = sh0.w;
                     const V3 at = o + t_sup * d;                            // ray_normalized_at :103-105
                     V3 normal = (at - center) / radius;
                     const bool front_face = dot3(normal, d) <= 0.0f;
                     if (!front_face) normal = -normal;
 
                     // dyn_material_scatter, shader.wgsl:244-252
-                    V3 albedo = v3(1.0f, 1.0f, 1.0f), ndir = d;
+                    V3 albedo = v3(sh1.x, sh1.y, sh1.z), ndir = d;
                     bool scattered;
-                    if (m_ty == MRT_LAMBERTIAN) {                           // :203-216
-                        albedo = load_vec4_xyz(C->vec4_data, C->world.lambertians.albedo_base_idx + m_idx);
-                        ndir = normal + normalize3(rng_unit_ball(rng));     // unit_sphere :92-94
+                    // Lambertian and Metal both start with one unit-ball sample (:209 via :92-94, :236): one
+                    // rejection loop for the lanes of either kind (each lane still draws only its own numbers)
+                    const bool is_lambertian = m_ty == MRT_LAMBERTIAN, is_metal = m_ty == MRT_METAL;
+                    V3 ball = v3(0.0f, 0.0f, 0.0f);
+                    if (is_lambertian || is_metal) ball = rng_unit_ball(rng);
+                    if (is_lambertian) {                                    // :203-216
+                        ndir = normal + normalize3(ball);                   // unit_sphere :92-94
                         if (dot3(ndir, ndir) == 0.0f) ndir = normal;
                         scattered = true;
-                    } else if (m_ty == MRT_METAL) {                         // :228-242
+                    } else if (is_metal) {                                  // :228-242
                         const V3 refl = reflect3(d, normal);
-                        const float fuzz = C->f32_data[C->world.metals.fuzz_base_idx + m_idx];
-                        const V3 ball = rng_unit_ball(rng);
+                        const float fuzz = sh1.w;
                         ndir = v3(refl.x + fuzz * ball.x, refl.y + fuzz * ball.y, refl.z + fuzz * ball.z);
                         scattered = !(dot3(ndir, normal) <= 0.0f);
-                        albedo = load_vec4_xyz(C->vec4_data, C->world.metals.albedo_base_idx + m_idx);
                     } else if (m_ty == MRT_DIELECTRIC) {                    // extension, DESIGN.md §3
-                        const float ior = C->f32_data[C->world.dielectrics.ior_base_idx + m_idx];
+                        const float ior = sh1.w;
+                        albedo = v3(1.0f, 1.0f, 1.0f);
                         const float ri = front_face ? (1.0f / ior) : ior;
                         float cos_t = dot3(-d, normal);
                         cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;

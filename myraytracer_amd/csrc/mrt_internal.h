@@ -52,6 +52,9 @@ struct KParams {
     const float* vec4_data;     // r_vec4_f32_data (shader.wgsl:189-190), 4 floats per texel
     const float* f32_data;      // r_f32_data
     const int32_t* i32_data;    // r_i32_data
+    // per sphere, in the reference's order: (cx, cy, cz, radius) (albedo r, g, b, fuzz | ior) -- copies of the
+    // entries of the three arrays above that shading the sphere reads (api.cpp)
+    const float* shade;
     const uint32_t* seeds;      // r_rands: local_rows x W x [u32;4]
     const float* prev;          // r_framebuffer: local_rows x W x rgba
     float* out;                 // render target
