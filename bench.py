@@ -35,7 +35,7 @@ FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz: fp32 VALU lane-ops/s
 FLOP_PER_TEST = 23           # algorithmic flop per ray-sphere test (unfused count)
 VALU_PER_BOUND_TEST = 11     # as implemented: 10 fp32 VALU + 1 v_alignbit per cluster-bound test
-VALU_PER_MEMBER_TEST = 13    # 11 fp32 VALU + compare + list bookkeeping per member discriminant
+VALU_PER_MEMBER_TEST = 13    # 11 fp32 VALU + compare + queue bookkeeping per member discriminant
 
 WORKLOADS = {   # n_gpus -> (width, height, spp)
     1: (1920, 1080, 512),
@@ -207,10 +207,11 @@ def main():
                          "note": "kernel_ms = mean launch duration (HIP events on its stream); launches of consecutive "
                                  "frames overlap, so it is longer than ms_per_step",
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "valu": {"note": "the binding resource is fp32 VALU issue.  `algorithmic_*` = what the reference's linear scan "
-                             "(one test per sphere per world_hit, 23 flop each) would execute; the kernel sweeps cluster bounds "
-                             "and evaluates member discriminants only for candidate clusters, so the algorithmic rate may exceed "
-                             "the executed one and the fp32 peak; `executed_*` is what the kernel ran",
+            "valu": {"note": "the binding resource is VALU issue.  `algorithmic_*` = what the reference's linear scan "
+                             "(one test per sphere per world_hit, 23 flop each) would execute; the kernel sweeps the top level "
+                             "of a bounding-sphere hierarchy and evaluates member discriminants only under candidate bounds, so "
+                             "the algorithmic rate may exceed the executed one and the fp32 peak; `executed_*` is what the "
+                             "kernel ran (bound tests: the swept top level only)",
                      "algorithmic_sphere_tests_per_launch": tests_per_launch,
                      "algorithmic_tflops": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12, "peak_tflops": FP32_PEAK_TFLOPS,
                      "mean_bounces_per_sample": hits / total_samples if total_samples else None,

@@ -20,9 +20,11 @@ for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "render_kernel<" in r["Kernel_Name"] and "true>(" not in r["Kernel_Name"].split("render_kernel")[1][:14].replace("<true, false>", ""):
-            pass
-        if "render_kernel" in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]:      # skip the PILOT instantiation
+        name = r["Kernel_Name"]
+        if "render_kernel<" not in name:
+            continue
+        targs = [t.strip() for t in name.split("render_kernel<")[1].split(">")[0].split(",")]    # COUNT, PILOT, CTR, SMALL
+        if targs[1] == "false":                                                                   # skip the PILOT instantiation
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         vals[k] = sum(v) / len(v)
