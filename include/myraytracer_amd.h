@@ -259,6 +259,23 @@ int mrt_scene_cover(uint64_t scene_seed, int dielectric, mrt_sphere* out, size_t
 /* 10k-sphere stress scene (C5): ground + n_side x n_side jittered grid, 80/15/5 % L/M/D */
 int mrt_scene_stress(uint64_t scene_seed, uint32_t n_side, mrt_sphere* out, size_t cap, mrt_camera* cam_out);
 
+/* Scenes as data: a line-oriented text file holding what api::World (lib.rs:611-639,
+ * hard-coded in the reference, lib.rs:687-720) and the camera extension hold:
+ *     # comment
+ *     camera pinhole
+ *     camera lookat <from xyz> <at xyz> <up xyz> <vfov deg> <defocus angle deg> <focus dist>
+ *     sphere <centre xyz> <radius> lambertian <albedo rgb>
+ *     sphere <centre xyz> <radius> metal <albedo rgb> <fuzz>
+ *     sphere <centre xyz> <radius> dielectric <ior>
+ *     sphere <centre xyz> <radius> material <ty> <albedo rgb> <param>     (any other MaterialTy: absorbs)
+ * Sphere order = the reference's sphere index order (it decides ties, shader.wgsl:291-296).  Numbers are
+ * written with 9 significant digits, so save -> load reproduces every f32 bit.
+ * mrt_scene_load returns the number of spheres in the file (writes min(cap, n)) or a negative mrt_status
+ * (-MRT_ERR_IO, -MRT_ERR_BAD_SCENE; mrt_last_error(NULL) names the line); *has_camera = 1 if the file has a
+ * camera line (cam_out filled), else 0 (cam_out = the reference's pinhole). */
+int mrt_scene_save(const char* path, const mrt_sphere* spheres, size_t n, const mrt_camera* cam);
+int mrt_scene_load(const char* path, mrt_sphere* out, size_t cap, mrt_camera* cam_out, int* has_camera);
+
 /* ------------------------------------------------------------------ image output (host only) */
 
 /* rgba: height*width*4 floats, row 0 = bottom (as read back).  PFM keeps linear floats

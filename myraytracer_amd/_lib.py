@@ -21,7 +21,7 @@ EXPORTS = [
     "mrt_framebuffer_device_ptr", "mrt_read_framebuffer", "mrt_read_counters", "mrt_last_kernel_ms",
     "mrt_kernel_ms_history", "mrt_debug_read_counters", "mrt_debug_wave_log", "mrt_debug_set_tile_sort", "mrt_debug_set_cluster_factor", "mrt_debug_set_hierarchy", "mrt_debug_read_pixel_costs", "mrt_debug_set_schedule",
     "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_scene_default", "mrt_scene_cover",
-    "mrt_scene_stress", "mrt_write_pfm", "mrt_write_ppm",
+    "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
 ]
 
 
@@ -142,6 +142,8 @@ def load():
         "mrt_scene_default": (i32, [vp, sz]),
         "mrt_scene_cover": (i32, [u64, i32, vp, sz, P(MrtCamera)]),
         "mrt_scene_stress": (i32, [u64, u32, vp, sz, P(MrtCamera)]),
+        "mrt_scene_save": (i32, [C.c_char_p, vp, sz, P(MrtCamera)]),
+        "mrt_scene_load": (i32, [C.c_char_p, vp, sz, P(MrtCamera), P(C.c_int)]),
         "mrt_write_pfm": (i32, [C.c_char_p, vp, u32, u32]),
         "mrt_write_ppm": (i32, [C.c_char_p, vp, u32, u32]),
     }

@@ -7,6 +7,7 @@ reference's toolchain (Rust) is not in this image, so this mirror is Python over
 INTEGRATION.md shows the Rust binding of the same ABI.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -182,6 +183,29 @@ def scene_stress(scene_seed: int = 1, n_side: int = 100):
     if n < 0 or n > len(out):
         raise MrtError(-n if n < 0 else 6, "mrt_scene_stress")
     return out[:n].copy(), Camera._from_c(cam)
+
+
+def save_scene(path: str, spheres, cam: Optional[Camera] = None):
+    """Write a scene file (format: include/myraytracer_amd.h, mrt_scene_save).  cam=None writes no camera line."""
+    arr = spheres.to_array() if isinstance(spheres, World) else np.ascontiguousarray(spheres, SPHERE_DTYPE)
+    c = cam._c() if cam is not None else None
+    st = _lib.load().mrt_scene_save(os.fsencode(path), arr.ctypes.data, len(arr), C.byref(c) if c is not None else None)
+    if st != 0:
+        raise MrtError(st, "mrt_scene_save", _lib.load().mrt_last_error(None).decode())
+
+
+def load_scene(path: str):
+    """Read a scene file -> (spheres, camera or None if the file has no camera line)."""
+    L = _lib.load()
+    cam, has = MrtCamera(), C.c_int(0)
+    n = L.mrt_scene_load(os.fsencode(path), None, 0, C.byref(cam), C.byref(has))
+    if n < 0:
+        raise MrtError(-n, "mrt_scene_load", L.mrt_last_error(None).decode())
+    out = np.zeros(n, SPHERE_DTYPE)
+    n2 = L.mrt_scene_load(os.fsencode(path), out.ctypes.data, len(out), C.byref(cam), C.byref(has))
+    if n2 != n:
+        raise MrtError(-n2 if n2 < 0 else 6, "mrt_scene_load")
+    return out, (Camera._from_c(cam) if has.value else None)
 
 
 def write_image(path: str, rgba: np.ndarray):

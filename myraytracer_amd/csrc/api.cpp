@@ -428,6 +428,8 @@ hipError_t sync_all(mrt_ctx* c) {
 
 }  // namespace
 
+namespace mrt { void set_global_error(const char* msg) { g_err = msg ? msg : ""; } }
+
 extern "C" {
 
 int mrt_abi_version(void) { return MRT_ABI_VERSION; }

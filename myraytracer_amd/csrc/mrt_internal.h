@@ -69,6 +69,9 @@ struct KParams {
     unsigned long long* wave_log;  // diagnostic (-DMRT_STAMPS builds): 4 x u64 per wave, or null
 };
 
+// api.cpp: message behind mrt_last_error(NULL), for failures of entry points that have no context
+void set_global_error(const char* msg);
+
 // host-callable launchers (kernels.hip)
 // queue reset + n_waves persistent render waves (a pilot launch also runs its cost-only finalize)
 int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream);

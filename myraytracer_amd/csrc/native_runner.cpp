@@ -17,14 +17,15 @@ static void usage() {
     std::fprintf(stderr,
         "usage: native_runner [--width N] [--height N] [--samples-per-frame N] [--ray-depth N]\n"
         "                     [--max-framebuffer-weight F] [--frames N] [--seed N]\n"
-        "                     [--scene default|cover|cover-glass|stress] [--out FILE.pfm|FILE.ppm] [--device N]\n");
+        "                     [--scene default|cover|cover-glass|stress | --scene-file FILE] [--save-scene FILE]\n"
+        "                     [--out FILE.pfm|FILE.ppm] [--device N]\n");
 }
 
 int main(int argc, char** argv) {
     mrt_args args;
     mrt_args_default(&args);
     uint32_t frames = 1; uint64_t seed = 1; int device = 0;
-    std::string scene = "default", out;
+    std::string scene = "default", scene_file, save_scene, out;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i], v;
         size_t eq = a.find('=');
@@ -40,6 +41,8 @@ int main(int argc, char** argv) {
         else if (a == "--frames") frames = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
         else if (a == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10);
         else if (a == "--scene") scene = v;
+        else if (a == "--scene-file") scene_file = v;
+        else if (a == "--save-scene") save_scene = v;
         else if (a == "--out") out = v;
         else if (a == "--device") device = std::atoi(v.c_str());
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return 2; }
@@ -49,12 +52,23 @@ int main(int argc, char** argv) {
     std::vector<mrt_sphere> spheres(70000);
     mrt_camera cam; std::memset(&cam, 0, sizeof cam);
     int n;
-    if (scene == "default") n = mrt_scene_default(spheres.data(), spheres.size());
+    if (!scene_file.empty()) {
+        // scenes as data: count first, then read
+        int has_cam = 0;
+        n = mrt_scene_load(scene_file.c_str(), nullptr, 0, &cam, &has_cam);
+        if (n >= 0) { spheres.resize((size_t)n + 1); n = mrt_scene_load(scene_file.c_str(), spheres.data(), spheres.size(), &cam, &has_cam); }
+        if (n < 0) { std::fprintf(stderr, "%s: %s (%s)\n", scene_file.c_str(), mrt_status_string(-n), mrt_last_error(nullptr)); return 1; }
+    }
+    else if (scene == "default") n = mrt_scene_default(spheres.data(), spheres.size());
     else if (scene == "cover") n = mrt_scene_cover(1, 0, spheres.data(), spheres.size(), &cam);
     else if (scene == "cover-glass") n = mrt_scene_cover(1, 1, spheres.data(), spheres.size(), &cam);
     else if (scene == "stress") n = mrt_scene_stress(1, 100, spheres.data(), spheres.size(), &cam);
     else { std::fprintf(stderr, "unknown scene %s\n", scene.c_str()); return 2; }
     if (n < 0) { std::fprintf(stderr, "scene generation failed\n"); return 1; }
+    if (!save_scene.empty()) {
+        const int ss = mrt_scene_save(save_scene.c_str(), spheres.data(), (size_t)n, &cam);
+        if (ss != MRT_OK) { std::fprintf(stderr, "%s: %s (%s)\n", save_scene.c_str(), mrt_status_string(ss), mrt_last_error(nullptr)); return 1; }
+    }
 
     mrt_ctx* ctx = nullptr;
     int st = mrt_create(&args, seed, device, &ctx);

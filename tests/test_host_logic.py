@@ -109,3 +109,37 @@ def test_image_writers(mrt, tmp_path):
     assert raw.startswith(b"P6\n4 3\n255\n")
     body = np.frombuffer(raw[len(b"P6\n4 3\n255\n"):], np.uint8).reshape(3, 4, 3)
     assert body[2, 0, 0] == 255 and body[0, 0, 2] == 128 and body[1].sum() == 0     # flipped, gamma 2
+
+
+def test_scene_files_round_trip_every_bit(mrt, tmp_path):
+    """Scenes as data: save -> load reproduces every sphere field and the camera bit for bit."""
+    cases = [(mrt.scene_default(), None), mrt.scene_cover(1, True), mrt.scene_cover(7, False), mrt.scene_stress(2, 12)]
+    odd = np.zeros(4, mrt.SPHERE_DTYPE)
+    odd[0] = ((1e-30, -3.4e38, 0.1), -0.5, 1, (0.1, 0.2, 0.3), -0.0)        # Lambertian with a non-canonical param
+    odd[1] = ((1 / 3, 2 / 3, 1e6), 1e-3, 3, (0.5, 1.0, 1.0), 1.33)          # Dielectric with a colour
+    odd[2] = ((0, 0, 0), 1.0, 7, (0.25, 0.5, 0.75), 9.0)                    # unknown MaterialTy: absorbs
+    odd[3] = ((1, 2, 3), 4.0, 2, (0.9, 0.8, 0.7), 0.123456789)
+    cases.append((odd, mrt.Camera(1, (0.1, 0.2, 0.3), (1, 1, 1), (0, 1, 0), 33.3, 0.7, 9.99)))
+    for i, (sc, cam) in enumerate(cases):
+        path = str(tmp_path / f"scene{i}.txt")
+        mrt.save_scene(path, sc, cam)
+        sc2, cam2 = mrt.load_scene(path)
+        assert sc2.tobytes() == np.ascontiguousarray(sc, mrt.SPHERE_DTYPE).tobytes()
+        assert (cam2 is None) == (cam is None)
+        if cam is not None:
+            assert bytes(cam2._c()) == bytes(cam._c())
+
+
+def test_scene_file_errors_name_the_line(mrt, tmp_path):
+    bad = tmp_path / "bad.txt"
+    bad.write_text("# ok\nsphere 0 0 0 1 lambertian 0.5 0.5 0.5\nsphere 0 0 0 1 velvet 1 2 3\n")
+    with pytest.raises(mrt.MrtError) as e:
+        mrt.load_scene(str(bad))
+    assert "line 3" in str(e.value)
+    with pytest.raises(mrt.MrtError):
+        mrt.load_scene(str(tmp_path / "missing.txt"))
+    ok = tmp_path / "hand.txt"
+    ok.write_text("camera pinhole\n  sphere 0 -100.5 -1 100 lambertian 0.8 0.8 0   # ground\n\nsphere 1 0 -1 .5 metal .8 .6 .2 1\n")
+    sc, cam = mrt.load_scene(str(ok))
+    assert len(sc) == 2 and cam is not None and cam.mode == 0
+    assert sc[1]["material_ty"] == mrt.METAL and sc[1]["param"] == 1.0 and tuple(sc[0]["center"]) == (0.0, -100.5, -1.0)
