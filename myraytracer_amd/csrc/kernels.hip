@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
     unsigned long long mtests = 0;       // wave-uniform
 
 #ifdef MRT_STAMPS
-    uint64_t phase_[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t phase_[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t rounds_a_ = 0, rounds_b_ = 0, items_a_ = 0, items_b_ = 0;     // wave-uniform
     uint64_t last_ = __builtin_amdgcn_s_memtime();
     const uint64_t wave_t0_ = __builtin_amdgcn_s_memrealtime();
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                             total_rem -= n_new;
                             if (total_rem != 0u) incl = wave_incl_scan(rem);
                             lds_order();
-                            MRT_STAMP(2);
+                            MRT_STAMP(6);
                             continue;
                         }
 #pragma unroll
@@ -769,6 +769,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
             atomicAdd(P.counters + 4, (unsigned long long)mtests);     // wave-uniform
 #ifdef MRT_STAMPS
             for (int k = 0; k < 6; k++) atomicAdd(P.counters + 6 + k, (unsigned long long)phase_[k]);
+            atomicAdd(P.counters + 5, (unsigned long long)phase_[6]);
             atomicAdd(P.counters + 12, (unsigned long long)rounds_a_);
             atomicAdd(P.counters + 13, (unsigned long long)rounds_b_);
             atomicAdd(P.counters + 14, (unsigned long long)items_a_);

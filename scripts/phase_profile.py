@@ -15,8 +15,9 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     st.render(1); st.sync()
     raw = (C.c_uint64 * 16)()
     _lib.load().mrt_debug_read_counters(st._ctx, raw)
-    names = ["new_sample", "sweep", "walk: unpack + node rounds", "walk: root rounds", "shade", "release/refill/acquire"]
-    ph = [raw[6 + k] for k in range(6)]
+    names = ["new_sample", "sweep", "walk: node rounds", "walk: root rounds", "shade", "release/refill/acquire"]
+    ph = [raw[6 + k] for k in range(6)] + [raw[5]]
+    names = names + ["walk: owners unpack masks into items"]
     tot = sum(ph)
     print("kernel ms", st.last_kernel_ms(), "wave sweeps", raw[3] / 64)
     for n, v in zip(names, ph):
