@@ -99,7 +99,7 @@ int mrt_scene_cover(uint64_t scene_seed, int dielectric, mrt_sphere* out, size_t
 
 // Stress scene: ground + n_side^2 small spheres on a jittered unit grid, 80/15/5 % L/M/D.
 int mrt_scene_stress(uint64_t scene_seed, uint32_t n_side, mrt_sphere* out, size_t cap, mrt_camera* cam_out) {
-    if (n_side == 0 || n_side > 250) return -MRT_ERR_INVALID_ARG;
+    if (n_side == 0 || n_side > 1000) return -MRT_ERR_INVALID_ARG;    // 1000^2 + 1 <= kMaxSpheres
     Sink k{out, cap};
     SceneRng rng{scene_seed};
     k.push(make(0.0f, -1000.0f, 0.0f, 1000.0f, MRT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 0.0f));

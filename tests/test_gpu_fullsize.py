@@ -4,7 +4,7 @@ accumulation algebra, analytic sky rows)."""
 import numpy as np
 import pytest
 
-from common import gpu_render, to_oracle_camera, to_oracle_spheres
+from common import gpu_render, mismatch_report, oracle_render, to_oracle_camera, to_oracle_spheres
 
 pytestmark = pytest.mark.gpu
 
@@ -87,3 +87,13 @@ def test_default_scene_sky_rows_are_analytic(mrt):
     assert (top[:, 2] == 1.0).all() and (top[:, 3] == 1.0).all()
     assert ((top[:, 0] > 0.5) & (top[:, 0] < 0.76)).all()
     assert abs(float(got[..., :3].mean()) - 0.4164) < 0.01
+
+
+def test_hundred_thousand_spheres(mrt, oracle):
+    """10 x C5's sphere count: 99,857 spheres -> 4 hierarchy levels above 25k clusters, several sweep blocks."""
+    sc, cam = mrt.scene_stress(3, 316)
+    assert len(sc) > 99000
+    ref = oracle_render(oracle, sc, cam, 40, 24, 2, 6, 5)
+    got, c, _ = gpu_render(mrt, sc, cam, 40, 24, 2, 6, 5)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    assert c["sweep_records"] > 256          # more than one sweep block at the top level
