@@ -217,7 +217,7 @@ bool finite_in_range(float v, float lim) { return std::isfinite(v) && std::fabs(
 // centres, at a multiple of kClusterK near the median) down to groups of <= 8, and such a group is cut
 // into 4 + rest by trying every choice.  Spheres far larger than the median (a ground sphere) stay alone;
 // factor == 0 (diagnostic) gives every sphere a cluster of its own.  Consecutive clusters are kd siblings, which is what
-// the upper levels (build_hierarchy) group.  R is 6 % above the enclosing radius measured from the
+// the upper levels (build_hierarchy) group.  R is 1.5 % above the enclosing radius measured from the
 // f32-rounded centre: part of the conservativeness argument in DESIGN.md §4.  Clusters are padded to
 // kClusterK members and the list to a multiple of kGroup with never-hit records (-r^2 = +inf gives a
 // discriminant of -inf).
@@ -312,7 +312,7 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
         std::sort(g.begin(), g.end());
         double ctr[3];
         const double R = enclose(g.data(), (uint32_t)g.size(), ctr);
-        const float Rf = (float)(R * 1.06) + 1e-30f;     // rounding R to f32 moves it by 6e-8 R, the 6 % is for the proof
+        const float Rf = (float)(R * mrt::kBoundInflate) + 1e-30f;     // rounding R to f32 moves it by 6e-8 R, the 1.5 % is for the proof
         clusters.push_back(mrt::SphereRec{(float)ctr[0], (float)ctr[1], (float)ctr[2], -(Rf * Rf)});
         for (uint32_t m = 0; m < mrt::kClusterK; m++) {
             if (m < g.size()) {
@@ -333,7 +333,7 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
 
 // Upper levels of the hierarchy: level k+1 bounds 4 consecutive level-k nodes (consecutive along the
 // Morton curve, so neighbours in space); its bounding sphere is measured from the MEMBER spheres under
-// it, R = 1.06 x the enclosing radius from the f32-rounded centre, so the conservativeness argument of
+// it, R = kBoundInflate x the enclosing radius from the f32-rounded centre, so the conservativeness argument of
 // the clusters holds for every level.  Levels are added while the top has more than
 // top_target records (the sweep costs every ray one test per top record; a walk round costs about 1.5
 // wave-instructions per item).  Every level is padded to a multiple of 4 (the top: kGroup) with
@@ -404,7 +404,7 @@ void build_hierarchy(const float* centers4, const float* radii, uint32_t n, floa
                 for (int k = 0; k < 3; k++) { const double d = (double)centers4[4 * i + k] - ctr[k]; d2 += d * d; }
                 R = std::max(R, std::sqrt(d2) + std::fabs((double)radii[i]));
             }
-            const float Rf = (float)(R * 1.06) + 1e-30f;
+            const float Rf = (float)(R * mrt::kBoundInflate) + 1e-30f;
             par.push_back(mrt::SphereRec{(float)ctr[0], (float)ctr[1], (float)ctr[2], -(Rf * Rf)});
         }
         while (cur.size() % 4 != 0) cur.push_back(never);

@@ -8,13 +8,16 @@
 //     per-lane state machine: every trip of the wave's loop is one `world_hit` for every
 //     live lane, whichever sample / bounce that lane is on;
 //   * `world_hit` (shader.wgsl:314-329) is split into (1) a branch-free, conservative sweep over
-//     the bounding spheres of clusters of <= 4 neighbouring spheres -- the records are
-//     wave-uniform, so they are fetched by scalar loads into SGPRs (no LDS, no VGPRs, no per-lane
-//     bandwidth); each costs 10 fp32 VALU ops + 1 v_alignbit that shifts the sign of the test
-//     into a per-lane 16-record bitmask kept in LDS -- and (2) a per-lane walk over the lane's
-//     candidate clusters that evaluates the reference's discriminant for their members and then
-//     its sqrt / divide / range tests (shader.wgsl:286-296) for the few with disc >= 0, accepting
-//     lexicographically by (t, sphere index), which is what the reference's index-order scan yields;
+//     the top level of a 4-ary hierarchy of bounding spheres (clusters of <= 4 neighbouring spheres,
+//     and for large scenes bounds of bounds) -- the records are wave-uniform, so they are fetched by
+//     scalar loads into SGPRs (no LDS, no VGPRs, no per-lane bandwidth); each costs 10 fp32 VALU ops +
+//     1 v_alignbit that shifts the sign of the test into a per-lane 16-record bitmask kept in LDS --
+//     and (2) a COOPERATIVE walk: the candidates of all 64 rays become work items (owner lane, node)
+//     in small LDS queues and every round 64 lanes take 64 items, whoever owns them: node rounds
+//     evaluate the reference's discriminant for the 4 members of a cluster (or the conservative test
+//     for the 4 children of an inner node), root rounds its sqrt / divide / range tests
+//     (shader.wgsl:286-296) for members with disc >= 0 and merge them into the owner's slot by a
+//     64-bit LDS minimum over (t, sphere index), which is what the reference's index-order scan yields;
 //   * persistent waves pull 8x8 tiles from one global heaviest-first queue and a lane that
 //     finishes its pixel takes the next waiting one (render_kernel);
 //   * finalize_kernel turns the per-pixel colour sums into the framebuffer: one coalesced
@@ -129,10 +132,10 @@ __device__ __forceinline__ void smem_wait_then_load8(Sph8& cur, Sph8& nxt, SphQu
                  : "+s"(cur.lo), "+s"(cur.hi), "=&s"(nxt.lo), "=&s"(nxt.hi), "+v"(bits) : "s"(p));
 }
 // The sweep's CONSERVATIVE line-vs-bounding-sphere test (10 fp32 VALU + 1 v_alignbit): with `ds` the
-// ray direction stretched by (1 + 3e-5), S = (oc.ds)^2 - (oc.oc - R^2) is >= 0 whenever the
+// ray direction stretched by kBoundStretch (1 + 1e-4), S = (oc.ds)^2 - (oc.oc - R^2) is >= 0 whenever the
 // reference's discriminant b*b - a*c (shader.wgsl:277-282) of ANY sphere inside the bound is >= 0:
-// the stretch adds >= 5e-5*|oc|^2 of slack against <= 3.2e-5*|oc|^2 of accumulated rounding error
-// and R is 6 % larger than the enclosing radius (proof sketch: DESIGN.md §4).  False positives only
+// the stretch adds >= 1.9e-4*|oc|^2 of slack against <= 1.2e-4*|oc|^2 of accumulated rounding error
+// and R is 1.5 % larger than the enclosing radius (proof sketch: DESIGN.md §4).  False positives only
 // cost a discriminant evaluation; a false negative cannot happen.  sign(S) is shifted into `bits`.
 __device__ __forceinline__ void test1(float cx, float cy, float cz, float neg_R2, V3 o, V3 ds, uint32_t& bits) {
     const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
@@ -441,7 +444,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                                  __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff()) ||
                                !(a > 0.99999f && a < 1.00001f);
             const bool usable = trace && !weird;
-            const V3 ds = v3(d.x * 1.00003f, d.y * 1.00003f, d.z * 1.00003f);
+            const V3 ds = v3(d.x * kBoundStretch, d.y * kBoundStretch, d.z * kBoundStretch);
             // every lane leaves its ray where whoever picks up one of its work items finds it
             rays[2u * lane + 0u] = make_float4(o.x, o.y, o.z, d.x);
             rays[2u * lane + 1u] = make_float4(d.y, d.z, __uint_as_float((uint32_t)kNoHitKey), __uint_as_float((uint32_t)(kNoHitKey >> 32)));
@@ -571,7 +574,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                         // Read q takes child (q + node/4) % 4, so that the 64 lanes of one read spread
                         // over all 16 LDS slots (4 banks each) instead of the 4 that child q alone maps to.
                         const bool inner = kLvMax >= 2 && k >= 2;
-                        const float sc = inner ? 1.00003f : 1.0f, ra_eff = inner ? 1.0f : ra;
+                        const float sc = inner ? kBoundStretch : 1.0f, ra_eff = inner ? 1.0f : ra;
                         const V3 re = v3(rd.x * sc, rd.y * sc, rd.z * sc);
                         uint32_t cbase = 0;                 // first record of the children's level
 #pragma unroll

@@ -13,6 +13,10 @@ constexpr uint32_t kGroup = 8;           // records per scalar-load group; the s
 constexpr uint32_t kClusterK = 4;        // spheres per sweep record (cluster)
 constexpr uint32_t kMaxSpheres = 1u << 20;
 constexpr uint32_t kMaxLevels = 4;       // levels of bounding spheres above the member spheres
+// Conservativeness of a bounding-sphere test: the ray direction is stretched by kBoundStretch
+// in the test and the stored radius is kBoundInflate x the enclosing radius.
+constexpr float kBoundStretch = 1.0001f;
+constexpr double kBoundInflate = 1.015;
 constexpr uint32_t kMaxDirect = 4;       // very large spheres tested by every ray directly, outside the hierarchy
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
