@@ -126,9 +126,9 @@ typedef struct {
     uint64_t rng_draws;            /* xoshiro128+ outputs consumed */
     uint64_t lane_slots;           /* 64 x trips of each wave's bounce loop: world_hit_calls / lane_slots
                                       = SIMD lane utilisation of the kernel (diagnostic, not in the oracle) */
-    uint64_t member_tests;         /* per-sphere discriminants evaluated for the members of candidate clusters */
-    uint64_t sweep_records;        /* cluster records the sweep tests per world_hit (not accumulated): executed
-                                      bound tests = world_hit_calls * sweep_records */
+    uint64_t member_tests;         /* per-sphere discriminants evaluated (members of candidate clusters + directly tested spheres) */
+    uint64_t sweep_records;        /* top-level bound records the sweep tests per world_hit (not accumulated): executed
+                                      bound tests of the sweep = world_hit_calls * sweep_records */
 } mrt_counters;
 
 typedef struct mrt_ctx mrt_ctx;
@@ -222,8 +222,8 @@ int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since c
 int mrt_debug_read_counters(mrt_ctx* ctx, uint64_t out[16]);
 /* Diagnostic: per-pixel cost (bounce-loop trips) of the last frame, local_rows*width u32. */
 int mrt_debug_read_pixel_costs(mrt_ctx* ctx, uint32_t* out, size_t cap);
-/* Diagnostic / tuning: growth factor of the sweep's sphere clusters (0 = one sphere per record),
- * used by the next mrt_set_world* call. */
+/* Diagnostic / tuning: 0 = one sphere per cluster record, > 0 = clusters of up to 4 spheres (the value itself
+ * is no longer used); takes effect at the next mrt_set_world* call. */
 int mrt_debug_set_cluster_factor(mrt_ctx* ctx, float factor);
 /* Diagnostic / tuning: depth of the bounding-sphere hierarchy built by the next mrt_set_world* call:
  * levels are added (up to max_levels, 1..4) while the top level has more than top_target records. */

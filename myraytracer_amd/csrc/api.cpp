@@ -386,8 +386,8 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
     }
 }
 
-// Upper levels of the hierarchy: level k+1 bounds 4 consecutive level-k nodes (consecutive along the
-// Morton curve, so neighbours in space); its bounding sphere is measured from the MEMBER spheres under
+// Upper levels of the hierarchy: level k+1 bounds 4 consecutive level-k nodes (consecutive in kd order,
+// so neighbours in space); its bounding sphere is measured from the MEMBER spheres under
 // it, R = kBoundInflate x the enclosing radius from the f32-rounded centre, so the conservativeness argument of
 // the clusters holds for every level.  Levels are added while the top has more than
 // top_target records (the sweep costs every ray one test per top record; a walk round costs about 1.5
