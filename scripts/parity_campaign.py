@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Dev helper (GPU box): a long randomised parity campaign, HIP vs oracle, bit for bit.
+   python scripts/parity_campaign.py [n_cases] [first_seed]
+Random scenes as in tests/test_gpu_random_scenes.py plus far / tiny / clustered / planar layouts, scene sizes up
+to a few thousand spheres, random hierarchy depth rules.  Prints one line per failure and a summary."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import myraytracer_amd as M
+from oracle import pyoracle as O
+from common import gpu_render, oracle_render, mismatch_report
+
+def scene(rng, n):
+    sc = np.zeros(n, M.SPHERE_DTYPE)
+    layout = rng.integers(0, 5)
+    scale = float(10.0 ** rng.uniform(-2, 4)) if rng.random() < 0.4 else 1.0
+    off = rng.uniform(-1, 1, 3) * (float(10.0 ** rng.uniform(0, 6)) if rng.random() < 0.3 else 0.0)
+    for i in range(n):
+        kind = rng.integers(0, 12)
+        if layout == 1:      # planar grid, like the cover scene
+            c = np.array([rng.uniform(-8, 8), 0.2, rng.uniform(-8, 8)]); r = rng.uniform(0.05, 0.3)
+        elif layout == 2:    # tight blobs
+            c = rng.integers(-3, 4, 3) * 2.0 + rng.normal(0, 0.15, 3); r = rng.uniform(0.02, 0.4)
+        elif layout == 3:    # concentric / coincident
+            c = np.array([0.0, 0.0, -3.0]) + (rng.normal(0, 1e-3, 3) if rng.random() < 0.5 else 0); r = 0.3 + 0.002 * (i % 97)
+        else:
+            c = rng.uniform(-4, 4, 3); r = rng.uniform(0.1, 1.5)
+        if kind == 0: c = np.array([rng.uniform(-5, 5), -rng.uniform(50, 2000), rng.uniform(-5, 5)]); r = abs(c[1]) - rng.uniform(0, 1)
+        elif kind == 1: r = rng.uniform(1e-3, 2e-2)
+        elif kind == 2: r = -r
+        ty = int(rng.integers(1, 4))
+        param = float(rng.uniform(0, 1.2)) if ty == 2 else float(rng.choice([1.0, 1.33, 1.5, 2.4, 0.7]))
+        sc[i] = (tuple(c * scale + off), r * scale, ty, tuple(rng.uniform(0.05, 1.0, 3)), param)
+    return sc, scale, off
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+    fails, skipped, t0 = 0, 0, time.time()
+    for case in range(first, first + n_cases):
+        rng = np.random.default_rng(case)
+        n = int(rng.choice([1, 3, 8, 17, 64, 100, 257, 300, 520, 1025, 1500, 3000]))
+        sc, scale, off = scene(rng, n)
+        if rng.random() < 0.25:
+            cam = None
+        else:
+            lf = rng.uniform(-6, 6, 3) * scale + off
+            la = rng.uniform(-1, 1, 3) * scale + off
+            cam = M.Camera(1, tuple(lf), tuple(la), (0.1 * rng.normal(), 1.0, 0.1 * rng.normal()), float(rng.uniform(5, 100)),
+                           float(rng.choice([0.0, 0.0, 0.5, 3.0])), float(rng.uniform(0.5, 12) * scale))
+        w, h = int(rng.integers(8, 80)), int(rng.integers(8, 48))
+        spp, depth = int(rng.choice([1, 2, 3, 5])), int(rng.choice([1, 2, 5, 13, 50]))
+        seed = int(rng.integers(0, 2 ** 62))
+        hier = (int(rng.integers(1, 5)), int(rng.choice([1, 4, 16, 64, 256])))
+        lim = max(float(np.abs(sc["center"]).max()), float(np.abs(sc["radius"]).max()))
+        if lim > 5e6:            # the ABI rejects |v| > 1e7
+            skipped += 1
+            continue
+        cnt = O.Counters()
+        ref = oracle_render(O, sc, cam, w, h, spp, depth, seed, 1, 1.0, counters=cnt)
+        with M.State(M.Args(w, h, spp, depth, 1.0), seed=seed) as st:
+            st.debug_set_hierarchy(*hier)
+            st.set_world(sc)
+            if cam is not None: st.set_camera(cam)
+            st.render(1)
+            got, c = st.read_framebuffer(), st.read_counters()
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        ok = same.all() and c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
+        if not ok:
+            fails += 1
+            print(f"FAIL case {case}: n={n} {w}x{h}x{spp} depth {depth} hier {hier} scale {scale:.3g}: {mismatch_report(got, ref)}", flush=True)
+        if (case - first) % 25 == 24:
+            print(f"... {case - first + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+    print(f"campaign: {n_cases} cases ({skipped} skipped: out of the ABI's coordinate range), {fails} failures")
+    sys.exit(1 if fails else 0)
+
+if __name__ == "__main__":
+    main()
