@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                 lds_order();
 
                 // ---- cooperative walk over this block's candidates
-                uint32_t wm = 0, wfirst = 0;              // owner side: the chunk mask being unpacked, its first cluster id
+                uint32_t wm = 0, ebase = 0;               // owner side: see the unpacking loop
                 uint32_t incl = wave_incl_scan(rem);
                 uint32_t total_rem = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 uint32_t qn[kLvMax + 1];
@@ -528,20 +528,32 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                             const uint32_t room = gen_cap - n_top;
                             const uint32_t n_new = total_rem < room ? total_rem : room;
                             entry_t* const dst = queues + levels * kQueueCap + n_top;
-                            uint32_t p = excl;
-                            while ((nz | wm) != 0u && p < n_new) {
-                                if (wm == 0u) {
-                                    const uint32_t cc = (uint32_t)__builtin_ctz(nz);
-                                    nz &= nz - 1u;
-                                    wm = masks[cc * 64u];
-                                    wfirst = blk + cc * kChunk;
+                            // wm: the chunk mask being unpacked, in the TOP 16 bits (clz = record within the chunk);
+                            // ebase: owner bits | first record id of that chunk
+                            entry_t* wp = dst + excl;
+                            auto refill = [&]() {
+                                const uint32_t cc = (uint32_t)__builtin_ctz(nz);
+                                nz &= nz - 1u;
+                                wm = (uint32_t)masks[cc * 64u] << 16;
+                                ebase = (lane << kIdBits) | (blk + cc * kChunk);
+                            };
+                            if (total_rem <= room) {             // the usual case: everything fits, no bound to watch
+                                while ((nz | wm) != 0u) {
+                                    if (wm == 0u) refill();
+                                    const uint32_t j = (uint32_t)__builtin_clz(wm);
+                                    wm ^= 0x80000000u >> j;
+                                    *wp++ = (entry_t)(ebase + j);
                                 }
-                                const uint32_t j = (uint32_t)__builtin_clz(wm) - 16u;
-                                wm &= ~(0x8000u >> j);
-                                dst[p] = (entry_t)((lane << kIdBits) | (wfirst + j));
-                                p++;
+                            } else {
+                                entry_t* const wend = dst + n_new;
+                                while ((nz | wm) != 0u && wp < wend) {
+                                    if (wm == 0u) refill();
+                                    const uint32_t j = (uint32_t)__builtin_clz(wm);
+                                    wm ^= 0x80000000u >> j;
+                                    *wp++ = (entry_t)(ebase + j);
+                                }
                             }
-                            rem -= p - excl;
+                            rem -= (uint32_t)(wp - (dst + excl));
 #pragma unroll
                             for (int lv = 1; lv <= kLvMax; lv++) if ((int)levels == lv) qn[lv] += n_new;
                             total_rem -= n_new;
