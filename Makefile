@@ -9,7 +9,7 @@ CLI      := $(LIBDIR)/native_runner
 # -ffp-contract=off: fma only where the source says fma (MRT-F32 rules).
 # -fno-vectorize -fno-slp-vectorize: v_pk_* fp32 is not faster than scalar VALU on gfx950
 # and SLP packing spends s_mov on SGPR pairs (profiles/r01_ubench_sphere_loop_*.txt).
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-vectorize -fno-slp-vectorize -Wall -Wextra -Wno-unused-parameter
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-vectorize -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wall -Wextra -Wno-unused-parameter
 SRCS     := $(CSRC)/kernels.hip $(CSRC)/tile_order.hip $(CSRC)/api.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
 HDRS     := $(CSRC)/mrt_internal.h include/myraytracer_amd.h
 

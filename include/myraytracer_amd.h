@@ -228,6 +228,10 @@ int mrt_debug_set_cluster_factor(mrt_ctx* ctx, float factor);
 /* Diagnostic / tuning: depth of the bounding-sphere hierarchy built by the next mrt_set_world* call:
  * levels are added (up to max_levels, 1..4) while the top level has more than top_target records. */
 int mrt_debug_set_hierarchy(mrt_ctx* ctx, uint32_t max_levels, uint32_t top_target);
+/* Diagnostic / tuning: which variant of the conservative sweep runs: 0 = automatic (matrix cores where the
+ * expanded test's slack is negligible for the scene and camera), 1 = SGPR-fed VALU sweep, 2 = matrix cores.
+ * Either way the image is the same; takes effect at the next redraw. */
+int mrt_debug_set_sweep(mrt_ctx* ctx, int mode);
 /* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */
 int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);
 /* Diagnostic / tuning: pilot samples per pixel, waves per CU (0 = automatic).  Before the first

@@ -355,6 +355,10 @@ class State:
         """Tuning / test hook: depth rule of the bounding-sphere hierarchy built by the next set_world()."""
         self._check(self._L.mrt_debug_set_hierarchy(self._ctx, max_levels, top_target), "mrt_debug_set_hierarchy")
 
+    def debug_set_sweep(self, mode: int):
+        """Tuning / test hook: 0 = automatic, 1 = SGPR-fed VALU sweep, 2 = matrix-core sweep (same image either way)."""
+        self._check(self._L.mrt_debug_set_sweep(self._ctx, mode), "mrt_debug_set_sweep")
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._check(self._L.mrt_last_kernel_ms(self._ctx, C.byref(ms)), "mrt_last_kernel_ms")

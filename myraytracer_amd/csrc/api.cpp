@@ -47,6 +47,10 @@ struct mrt_ctx {
     // device memory (all owned)
     mrt::SphereRec* d_spheres = nullptr;
     mrt::SphereRec* d_clusters = nullptr;  // bounding spheres the sweep tests (up to kClusterK spheres each)
+    uint16_t* d_top_mfma = nullptr;        // the top-level records as the MFMA A operand (build_top_mfma)
+    bool mfma_scene_ok = false;            // the expanded test's extra slack is negligible for this scene
+    double mfma_r2_ref = 0.0;              // median R^2 of the top level (camera check at launch)
+    int sweep_mode = 0;                    // 0 automatic, 1 SGPR-fed VALU sweep, 2 matrix-core sweep (mrt_debug_set_sweep)
     float* d_shade = nullptr;              // 8 floats per sphere: centre, radius, material colour, fuzz | ior
     mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
     uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
@@ -143,11 +147,12 @@ void free_world(mrt_ctx* c) {
     if (c->d_clusters) (void)hipFree(c->d_clusters);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_shade) (void)hipFree(c->d_shade);
+    if (c->d_top_mfma) (void)hipFree(c->d_top_mfma);
     if (c->d_member_index) (void)hipFree(c->d_member_index);
     if (c->d_vec4) (void)hipFree(c->d_vec4);
     if (c->d_f32) (void)hipFree(c->d_f32);
     if (c->d_i32) (void)hipFree(c->d_i32);
-    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_shade = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
+    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_shade = nullptr; c->d_top_mfma = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
     c->have_world = false;
 }
 
@@ -468,8 +473,58 @@ void build_hierarchy(const float* centers4, const float* radii, uint32_t n, floa
         cur.swap(par);
         H.levels++;
     }
-    while (cur.empty() || cur.size() % mrt::kGroup != 0) cur.push_back(never);
+    while (cur.empty() || cur.size() % 32 != 0) cur.push_back(never);      // 32 = one tile of the matrix-core sweep
     H.top.swap(cur);
+}
+
+// The top level once more, as the A operand of the matrix-core sweep (kernels.hip, mfma_sweep_tile): per
+// tile of 32 records 64 lanes x 8 bf16, lane l = row (l & 31), k = 8 (l >> 5) + j:
+//     k 0..2 C_hi, 3..5 C_hi, 6..8 C_lo, 9..11 (1,1,1), 12..14 Ck (hi, mid, lo), 15: 0
+// where row m of tile t is record 32 t + 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3) -- the order in which the
+// MFMA result registers come out, so that the two 16-bit sign words per tile are the masks of chunks 2t and
+// 2t + 1.  Ck = C.C - R^2 - 2^-13 (C.C + R^2): the record's share of the slack that covers what the bf16
+// split drops.  A never-hit record gets Ck = 3e38 (finite: an infinity would turn the other
+// GEMM's 0 x Ck into NaN).  Also returns what set_world needs to decide whether the slack is negligible:
+// the largest C.C and the median R^2.
+constexpr double kMfmaSlack = 0x1p-13;
+uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40u);      // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+float bf16_value(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+void build_top_mfma(const std::vector<mrt::SphereRec>& top, std::vector<uint16_t>& out, double* max_c2, double* med_r2) {
+    const size_t tiles = top.size() / 32;
+    out.assign(tiles * 512, 0);
+    std::vector<double> r2s;
+    *max_c2 = 0.0;
+    const uint16_t one = bf16_rne(1.0f);
+    for (size_t t = 0; t < tiles; t++)
+        for (uint32_t m = 0; m < 32; m++) {
+            const mrt::SphereRec& r = top[32 * t + 16 * ((m >> 2) & 1u) + 4 * (m >> 3) + (m & 3u)];
+            float ck = 3.0e38f;
+            if (std::isfinite(r.neg_r2)) {
+                const double c2 = (double)r.cx * r.cx + (double)r.cy * r.cy + (double)r.cz * r.cz, R2 = -(double)r.neg_r2;
+                const double v = c2 - R2 - kMfmaSlack * (c2 + R2);
+                ck = (float)v;
+                if ((double)ck > v) ck = std::nextafterf(ck, -INFINITY);
+                *max_c2 = std::max(*max_c2, c2);
+                r2s.push_back(R2);
+            }
+            const float c[3] = {r.cx, r.cy, r.cz};
+            uint16_t hi[3], lo[3];
+            for (int k = 0; k < 3; k++) { hi[k] = bf16_rne(c[k]); lo[k] = bf16_rne(c[k] - bf16_value(hi[k])); }
+            const uint16_t k0 = bf16_rne(ck);
+            const float ck1 = ck - bf16_value(k0);
+            const uint16_t k1 = bf16_rne(ck1), k2 = bf16_rne(ck1 - bf16_value(k1));
+            const uint16_t kvals[16] = {hi[0], hi[1], hi[2], hi[0], hi[1], hi[2], lo[0], lo[1], lo[2], one, one, one, k0, k1, k2, 0};
+            uint16_t* o = out.data() + t * 512;
+            for (int k = 0; k < 16; k++) o[((k >> 3) * 32 + m) * 8 + (k & 7)] = kvals[k];
+        }
+    *med_r2 = 0.0;
+    if (!r2s.empty()) { std::nth_element(r2s.begin(), r2s.begin() + r2s.size() / 2, r2s.end()); *med_r2 = r2s[r2s.size() / 2]; }
 }
 
 // wait for everything this context has in flight (caller's stream and both side streams)
@@ -763,6 +818,17 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     HIP_TRY(c, upload((void**)&c->d_spheres, recs.data(), recs.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_clusters, hier.top.data(), hier.top.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_nodes, hier.nodes.data(), hier.nodes.size() * sizeof(mrt::SphereRec)));
+    {
+        std::vector<uint16_t> top_mfma;
+        double max_c2 = 0.0, med_r2 = 0.0;
+        build_top_mfma(hier.top, top_mfma, &max_c2, &med_r2);
+        HIP_TRY(c, upload((void**)&c->d_top_mfma, top_mfma.data(), top_mfma.size() * sizeof(uint16_t)));
+        // The matrix-core sweep inflates R^2 by 2^-13 (o.o + C.C + R^2); rays start in or around the scene.
+        // Selected where that stays below about a tenth of the typical R^2; mrt_redraw checks the camera's
+        // own distance the same way.
+        c->mfma_r2_ref = med_r2;
+        c->mfma_scene_ok = med_r2 > 0.0 && kMfmaSlack * 2.0 * max_c2 <= 0.1 * med_r2;
+    }
     HIP_TRY(c, upload((void**)&c->d_member_index, hier.member_index.data(), hier.member_index.size() * sizeof(uint32_t)));
     // what shading a hit on sphere i reads, gathered per sphere (bit copies of the SoA entries)
     std::vector<float> shade(8 * ((size_t)n ? (size_t)n : 1), 0.0f);
@@ -882,6 +948,12 @@ int mrt_redraw(mrt_ctx* c) {
     p.n_spheres = c->n_spheres;
     p.n_padded = c->n_padded;
     { const uint32_t ch = (c->n_padded + mrt::kChunk - 1) / mrt::kChunk; p.mask_chunks = ch < 16u ? ch : 16u; }
+    {
+        const double o2 = c->cam_raw.mode ? (double)c->cam_raw.origin[0] * c->cam_raw.origin[0] + (double)c->cam_raw.origin[1] * c->cam_raw.origin[1] +
+                                            (double)c->cam_raw.origin[2] * c->cam_raw.origin[2] : 0.0;
+        const bool cam_ok = kMfmaSlack * o2 <= 0.1 * c->mfma_r2_ref;
+        p.use_mfma = c->sweep_mode == 2 || (c->sweep_mode == 0 && c->mfma_scene_ok && cam_ok);
+    }
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
     p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) p.level_base[k] = c->level_base[k];
@@ -889,7 +961,7 @@ int mrt_redraw(mrt_ctx* c) {
     for (uint32_t k = 0; k < mrt::kMaxDirect; k++) p.direct[k] = c->direct[k];
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.cus = c->cus;
-    p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.shade = c->d_shade; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
+    p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.top_mfma = c->d_top_mfma; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.shade = c->d_shade; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
     p.seeds = c->d_seeds;
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
     p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
@@ -973,6 +1045,12 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
 int mrt_debug_set_cluster_factor(mrt_ctx* c, float factor) {
     if (!c || !(factor >= 0.0f)) return MRT_ERR_INVALID_ARG;
     c->cluster_factor = factor;
+    return MRT_OK;
+}
+
+int mrt_debug_set_sweep(mrt_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return MRT_ERR_INVALID_ARG;
+    c->sweep_mode = mode;
     return MRT_OK;
 }
 

@@ -155,6 +155,96 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
     test4(g.hi, o, ds, bits);
 }
 
+// ---- the same conservative test on the matrix cores -------------------------------------------------
+// Expanding S = (oc.ds)^2 - (oc.oc - R^2) with oc = o - C turns its two dot products into products of a
+// per-record vector with a per-ray vector:
+//     -(oc.ds) = C.ds - o.ds                 S = (oc.ds)^2 - o.o - U
+//     U        = -2 o.C + (C.C - R^2)
+// i.e. two [32 records] x [32 rays] GEMMs per tile.  The f32 MFMA runs on the vector FMA units (measured:
+// no overlap with VALU work), so the GEMMs run in bf16 on the matrix cores proper, with every f32 factor
+// split into bf16 pieces x = hi + lo (+ mid) and the cross products laid out along K = 16:
+//     k  0..2   C_hi (x,y,z)     . v_hi        v = ds for the first GEMM, -2 o for the second
+//     k  3..5   C_hi             . v_lo
+//     k  6..8   C_lo             . v_hi
+//     k  9..11  (1, 1, 1)        . (-o.ds as hi, mid, lo | 0, 0, 0)
+//     k 12..14  Ck (hi, mid, lo) . (0, 0, 0 | 1, 1, 1)                 Ck = C.C - R^2 (minus its slack)
+// so ONE A operand per tile serves both.  What the split drops (C_lo v_lo and the remainders: 3 x 2^-18 of
+// every product) and the f32 accumulation err by at most 2.5e-5 o.o + 5e-5 C.C in S; the
+// test gives away 2^-13 = 1.2e-4 of o.o + C.C + R^2: o.o is scaled by kMfmaRaySlack here and the host
+// lowers Ck by 2^-13 (C.C + R^2) (api.cpp, build_top_mfma).  That is no longer scale-free: the host selects
+// this variant only where it is small against R^2; elsewhere the SGPR-fed sweep above runs.
+// Operand layout (lane l, r = l & 31, h = l >> 5): A[record r][k = 8h + j], B[k = 8h + j][ray r], j = 0..7;
+// result register i of lane l is record (i&3) + 8(i>>2) + 4h for ray r.  v_permlane32_swap(a, b) =
+// {(a.lo, b.lo), (a.hi, b.hi)} builds the B operands of both 32-ray halves from a lane's own k 0..7 and
+// k 8..15 words and, applied to the two halves' sign words, hands every lane the signs of its OWN ray:
+// r[0] = the records with (row & 4) == 0, r[1] = the others.  The host stores the records of a tile in that
+// order, so r[0] / r[1] are the masks of chunks 2t / 2t+1.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr float kMfmaRaySlack = 1.0f - 0x1p-13f;
+struct MfmaRay { u32x4 bp[2], bu[2]; float kk[2]; };
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {          // two round-to-nearest conversions
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ void swap32(uint32_t a, uint32_t b, uint32_t& r0, uint32_t& r1) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    r0 = r[0];
+    r1 = r[1];
+}
+__device__ __forceinline__ void mfma_pack_ray(V3 v, float w0, float w1, float w2, bool ones, u32x4 out[2]) {
+    const V3 h = v3(bf16_round(v.x), bf16_round(v.y), bf16_round(v.z));
+    const V3 l = v3(v.x - h.x, v.y - h.y, v.z - h.z);           // exact; rounded to bf16 by the packing below
+    const uint32_t x0 = pk_bf16(h.x, h.y), x1 = pk_bf16(h.z, l.x), x2 = pk_bf16(l.y, l.z);      // k 0..5, 6..7 = x0
+    const uint32_t y0 = pk_bf16(h.z, w0), y1 = pk_bf16(w1, w2);                                   // k 8..11
+    const uint32_t y2 = ones ? 0x3F803F80u : 0u, y3 = ones ? 0x00003F80u : 0u;                     // k 12..15
+    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+    swap32(x0, y0, a0, b0);
+    swap32(x1, y1, a1, b1);
+    swap32(x2, y2, a2, b2);
+    swap32(x0, y3, a3, b3);
+    out[0] = u32x4{a0, a1, a2, a3};
+    out[1] = u32x4{b0, b1, b2, b3};
+}
+__device__ __forceinline__ MfmaRay mfma_ray_operands(V3 o, V3 ds) {
+    MfmaRay m;
+    const float nk0 = -dot3(o, ds);
+    const float n0 = bf16_round(nk0), n1 = bf16_round(nk0 - n0), n2 = (nk0 - n0) - n1;    // hi + mid + lo, each difference exact
+    mfma_pack_ray(ds, n0, n1, n2, false, m.bp);
+    mfma_pack_ray(v3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z), 0.0f, 0.0f, 0.0f, true, m.bu);
+    const float k1p = dot3(o, o) * kMfmaRaySlack;
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1p), __float_as_uint(k1p), false, false);
+    m.kk[0] = __uint_as_float(r[0]);
+    m.kk[1] = __uint_as_float(r[1]);
+    return m;
+}
+// one tile of 32 records against the wave's 64 rays; `a` = this lane's 8 bf16 of the tile's A operand
+// (api.cpp, build_top_mfma).  mA / mB: candidate masks (record i of the chunk at bit 15 - i) of the tile's two
+// chunks for this lane's own ray.
+__device__ __forceinline__ void mfma_sweep_tile(const u32x4 a, const MfmaRay& m, uint32_t& mA, uint32_t& mB) {
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16x8 av = __builtin_bit_cast(bf16x8, a);
+    uint32_t hb[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const f32x16 accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m.bp[h]), zero, 0, 0, 0);
+        const f32x16 accu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m.bu[h]), zero, 0, 0, 0);
+        uint32_t bb = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float S = __builtin_fmaf(accp[i], accp[i], -m.kk[h]) - accu[i];
+            bb = __builtin_amdgcn_alignbit(bb, __float_as_uint(S), 31);
+        }
+        hb[h] = bb;
+        __builtin_amdgcn_sched_barrier(0);      // one half's 32 accumulator registers at a time
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(hb[0], hb[1], false, false);
+    mA = ~r[0] & 0xFFFFu;
+    mB = ~r[1] & 0xFFFFu;
+}
+
 // Candidate masks: per wave kBlockChunks x 64 lanes of u16 (one 16-sphere sign mask per chunk
 // and lane), chunk-major so that the 64 lanes of one access touch 128 consecutive bytes.
 // Diagnostic build only (-DMRT_STAMPS, scripts/phase_profile.py): s_memtime shares of the
@@ -248,8 +338,8 @@ __device__ __forceinline__ KArgPtr cold_args() {
 // the walk gathers per item -- an L1 round trip per candidate cluster otherwise.  SMALL also means
 // that every node id fits 10 bits, so the work items are u16.
 constexpr uint32_t kWavesPerGroup = 4;
-template <bool COUNT, bool PILOT, bool CTR, bool SMALL>
-__global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KParams P) {
+template <bool COUNT, bool PILOT, bool CTR, bool SMALL, bool MFMA>
+__global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(5, 8))) render_kernel(const KParams P) {
     typedef typename Ent<SMALL>::type entry_t;
     constexpr uint32_t kIdBits = Ent<SMALL>::id_bits;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -474,14 +564,29 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                 if (COUNT) mtests += (unsigned long long)n_direct * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(usable));
             }
             uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
+            // MFMA variant of the sweep: per-ray operands of the two GEMMs, rays x records (see mfma_sweep_tile)
+            MfmaRay mr;
+            if (MFMA) mr = mfma_ray_operands(o, ds);
             for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
                 const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
+                uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
+                uint32_t rem = 0;                                       // this lane's candidate clusters in the block
+                if (MFMA) {
+                    // 32 records per tile = two 16-record chunks per lane and ray
+                    uint32_t c = 0;
+                    for (uint32_t i = blk; i < blk_end; i += 2u * kChunk, c += 2u) {
+                        uint32_t mA, mB;
+                        mfma_sweep_tile(reinterpret_cast<const u32x4*>(P.top_mfma)[(size_t)(i / 32u) * 64u + lane], mr, mA, mB);
+                        masks[c * 64u] = (uint16_t)mA;
+                        masks[(c + 1u) * 64u] = (uint16_t)mB;
+                        nz |= ((mA < 1u ? mA : 1u) << c) | ((mB < 1u ? mB : 1u) << (c + 1u));
+                        rem += (uint32_t)__builtin_popcount(mA | (mB << 16));
+                    }
+                } else {
                 // the 64 record SGPRs are live only during the block's sweep, not during its walk
                 Sph8 ga, gb;
                 smem_load8(ga, sph_quads, blk);
                 asm volatile("" : "=s"(gb.lo), "=s"(gb.hi));   // defined (uniform) on every path to the block's final wait
-                uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
-                uint32_t rem = 0;                                       // this lane's candidate clusters in the block
                 uint32_t c = 0;
                 for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
                     // the record count is padded to 8, not 16: the very last chunk may hold one group only
@@ -499,6 +604,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) render_kernel(const KPara
                 // the last prefetch is never consumed, but its destination SGPRs must stay reserved
                 // until it has landed
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ga.lo), "+s"(ga.hi), "+s"(gb.lo), "+s"(gb.hi));
+                }
                 MRT_STAMP(1);
                 if (!usable) { nz = 0; rem = 0; }         // idle lanes; "weird" lanes take the literal loop below
                 lds_order();
@@ -888,10 +994,13 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
     const uint32_t want = n_waves < p.n_tiles ? n_waves : p.n_tiles;
     dim3 grid((want + kWavesPerGroup - 1) / kWavesPerGroup), block(64 * kWavesPerGroup);
     const bool ctr = p.locals.rng_mode == MRT_RNG_COUNTER;
-#define MRT_LAUNCH(C_, P_, R_)                                                                        \
-    do {                                                                                              \
-        if (small) hipLaunchKernelGGL((render_kernel<C_, P_, R_, true>), grid, block, lds, st, p);    \
-        else hipLaunchKernelGGL((render_kernel<C_, P_, R_, false>), grid, block, lds, st, p);         \
+    const bool mfma = p.use_mfma != 0;
+#define MRT_LAUNCH(C_, P_, R_)                                                                                      \
+    do {                                                                                                            \
+        if (small && mfma) hipLaunchKernelGGL((render_kernel<C_, P_, R_, true, true>), grid, block, lds, st, p);    \
+        else if (small) hipLaunchKernelGGL((render_kernel<C_, P_, R_, true, false>), grid, block, lds, st, p);      \
+        else if (mfma) hipLaunchKernelGGL((render_kernel<C_, P_, R_, false, true>), grid, block, lds, st, p);       \
+        else hipLaunchKernelGGL((render_kernel<C_, P_, R_, false, false>), grid, block, lds, st, p);                \
     } while (0)
     if (pilot) {
         if (ctr) MRT_LAUNCH(false, true, true); else MRT_LAUNCH(false, true, false);
@@ -917,7 +1026,7 @@ int launch_finalize(const KParams& p, void* stream) {
 // how many waves of the render kernel one CU holds (occupancy API)
 int render_waves_per_cu(int* out) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false, false, false>, 64 * kWavesPerGroup, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false, false, false, false>, 64 * kWavesPerGroup, 0);
     *out = nb * (int)kWavesPerGroup;
     return (int)e;
 }

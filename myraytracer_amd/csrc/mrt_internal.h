@@ -44,6 +44,11 @@ struct KParams {
     // records (multiple of kGroup, padded with never-hit entries).  `nodes` holds levels 0..levels-1,
     // level k at level_base[k]; member_index[] is each member's index in the reference's sphere order.
     const SphereRec* clusters;
+    // the same top-level records as the A operand of the matrix-core sweep (kernels.hip, mfma_sweep_tile):
+    // per tile of 32 records 64 lanes x 8 bf16, record order within a tile permuted to the result layout;
+    // use_mfma selects that variant of the sweep (api.cpp decides per scene and camera)
+    const uint16_t* top_mfma;
+    uint32_t use_mfma;
     const SphereRec* nodes;
     const uint32_t* member_index;
     uint32_t levels, n_nodes, n_members, gen_cap;

@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "myraytracer_amd", "csrc", "kernels.hip")
-DEFAULT_FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-vectorize -fno-slp-vectorize"
+DEFAULT_FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-vectorize -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form"
 
 
 def sregs(text):
@@ -89,8 +89,13 @@ def check_kernel(name, lines):
                 if sregs(ops.split(",", 1)[1]) & dest:
                     errors.append(f"{name}: `{l}` (line {k}) reads {m.group(1)} while in flight")
             stack.extend(successors(k))
-    if loads == 0:
+    # render_kernel<COUNT, PILOT, CTR, SMALL, MFMA>: the matrix-core variant of the sweep (last argument
+    # true, mangled ...Lb1EEEv...) has no hand-issued scalar loads; every other one must have them
+    mfma_variant = "Lb1EEEv" in name
+    if loads == 0 and not mfma_variant:
         errors.append(f"{name}: no hand-issued s_load_dwordx16 found (sweep not recognised)")
+    if mfma_variant and not any("v_mfma_f32_32x32x16_bf16" in l for l in lines):
+        errors.append(f"{name}: matrix-core sweep variant without v_mfma_f32_32x32x16_bf16")
     return errors
 
 

@@ -61,6 +61,7 @@ def main():
         ref = oracle_render(O, sc, cam, w, h, spp, depth, seed, 1, 1.0, counters=cnt)
         with M.State(M.Args(w, h, spp, depth, 1.0), seed=seed) as st:
             st.debug_set_hierarchy(*hier)
+            st.debug_set_sweep(int(rng.integers(0, 3)))      # automatic / VALU / matrix-core sweep
             st.set_world(sc)
             if cam is not None: st.set_camera(cam)
             st.render(1)

@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/pmcq_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/p1 -o p1 -- python3 $REPO/scripts/quick_counters.py "$@" > $OUT/p1.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -o p2 -- python3 $REPO/scripts/quick_counters.py "$@" > $OUT/p2.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/p2 -o p2 -- python3 $REPO/scripts/quick_counters.py "$@" > $OUT/p2.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

@@ -15,6 +15,9 @@ def run(scene, w, h, spp, depth=50, frames=2, shard=None):
             from myraytracer_amd import _lib
             a_ = [int(x) for x in sched.split(",")]
             assert _lib.load().mrt_debug_set_schedule(st._ctx, a_[0], a_[1]) == 0
+        if os.environ.get("MRT_SWEEP"):       # 1 = SGPR-fed VALU sweep, 2 = matrix-core sweep
+            from myraytracer_amd import _lib
+            assert _lib.load().mrt_debug_set_sweep(st._ctx, int(os.environ["MRT_SWEEP"])) == 0
         if os.environ.get("MRT_HIER"):        # "max_levels,top_target"
             from myraytracer_amd import _lib
             h_ = [int(x) for x in os.environ["MRT_HIER"].split(",")]

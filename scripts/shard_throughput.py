@@ -7,6 +7,9 @@ w, h, spp, rank, world = (int(x) for x in sys.argv[1:6])
 K = int(sys.argv[6]) if len(sys.argv) > 6 else 4
 sp, cam = M.scene_cover(1, True)
 with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 1 else None) as st:
+    if os.environ.get("MRT_SWEEP"):       # 1 = SGPR-fed VALU sweep, 2 = matrix-core sweep
+        from myraytracer_amd import _lib
+        assert _lib.load().mrt_debug_set_sweep(st._ctx, int(os.environ["MRT_SWEEP"])) == 0
     if os.environ.get("MRT_HIER"):        # "max_levels,top_target"
         from myraytracer_amd import _lib
         h_ = [int(x) for x in os.environ["MRT_HIER"].split(",")]

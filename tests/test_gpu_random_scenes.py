@@ -125,3 +125,26 @@ def test_every_queue_overflows_in_a_deep_hierarchy(mrt, oracle):
             st.render(1)
             got = st.read_framebuffer()
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), f"hierarchy {max_levels},{top_target}: " + mismatch_report(got, ref)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_both_sweep_variants_give_the_same_image(mrt, oracle, mode):
+    """The sweep has two variants -- SGPR-fed VALU tests and bf16-split GEMMs on the matrix cores, whose slack
+    grows with |o|^2 + |C|^2 -- chosen per scene and camera.  Forced either way, near the origin or 3,000
+    units away from it (where the matrix-core variant makes every record a candidate), the image is the same."""
+    rng = np.random.default_rng(4242)
+    for n, off in [(300, 0.0), (300, 3000.0), (1500, 0.0), (40, 2.0e5)]:
+        sc = _random_scene(mrt, rng, n)
+        sc["center"] += np.float32(off)
+        cam = mrt.Camera(1, (5.0 + off, 3.0 + off, 6.0 + off), (off, off, off), (0.0, 1.0, 0.0), 50.0, 0.3, 7.0)
+        cnt = oracle.Counters()
+        ref = oracle_render(oracle, sc, cam, 48, 28, 2, 7, 31, counters=cnt)
+        with mrt.State(mrt.Args(48, 28, 2, 7, 1.0), seed=31) as st:
+            st.debug_set_sweep(mode)
+            st.set_world(sc)
+            st.set_camera(cam)
+            st.render(1)
+            got, c = st.read_framebuffer(), st.read_counters()
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        assert same.all(), f"sweep mode {mode}, n={n}, offset {off}: " + mismatch_report(got, ref)
+        assert c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
