@@ -166,9 +166,9 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 //     k  0..2   C_hi (x,y,z)     . v_hi        v = ds for the first GEMM, -2 o for the second
 //     k  3..5   C_hi             . v_lo
 //     k  6..8   C_lo             . v_hi
-//     k  9..11  (1, 1, 1)        . (-o.ds as hi, mid, lo | 0, 0, 0)
+//     k  9..11  (1, 1, 1)        . (-o.ds | o.o (minus its slack)), each as hi, mid, lo
 //     k 12..14  Ck (hi, mid, lo) . (0, 0, 0 | 1, 1, 1)                 Ck = C.C - R^2 (minus its slack)
-// so ONE A operand per tile serves both.  What the split drops (C_lo v_lo and the remainders: 3 x 2^-18 of
+// so ONE A operand per tile serves both, the second GEMM delivers U + o.o, and S is one fma of the two results.  What the split drops (C_lo v_lo and the remainders: 3 x 2^-18 of
 // every product) and the f32 accumulation err by at most 2.5e-5 o.o + 5e-5 C.C in S; the
 // test gives away 2^-13 = 1.2e-4 of o.o + C.C + R^2: o.o is scaled by kMfmaRaySlack here and the host
 // lowers Ck by 2^-13 (C.C + R^2) (api.cpp, build_top_mfma).  That is no longer scale-free: the host selects
@@ -182,7 +182,7 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr float kMfmaRaySlack = 1.0f - 0x1p-13f;
-struct MfmaRay { u32x4 bp[2], bu[2]; float kk[2]; };
+struct MfmaRay { u32x4 bp[2], bu[2]; };
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {          // two round-to-nearest conversions
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     const bf16x2 v = {(__bf16)lo, (__bf16)hi};
@@ -213,11 +213,9 @@ __device__ __forceinline__ MfmaRay mfma_ray_operands(V3 o, V3 ds) {
     const float nk0 = -dot3(o, ds);
     const float n0 = bf16_round(nk0), n1 = bf16_round(nk0 - n0), n2 = (nk0 - n0) - n1;    // hi + mid + lo, each difference exact
     mfma_pack_ray(ds, n0, n1, n2, false, m.bp);
-    mfma_pack_ray(v3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z), 0.0f, 0.0f, 0.0f, true, m.bu);
     const float k1p = dot3(o, o) * kMfmaRaySlack;
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(k1p), __float_as_uint(k1p), false, false);
-    m.kk[0] = __uint_as_float(r[0]);
-    m.kk[1] = __uint_as_float(r[1]);
+    const float q0 = bf16_round(k1p), q1 = bf16_round(k1p - q0), q2 = (k1p - q0) - q1;
+    mfma_pack_ray(v3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z), q0, q1, q2, true, m.bu);
     return m;
 }
 // one tile of 32 records against the wave's 64 rays; `a` = this lane's 8 bf16 of the tile's A operand
@@ -234,7 +232,7 @@ __device__ __forceinline__ void mfma_sweep_tile(const u32x4 a, const MfmaRay& m,
         uint32_t bb = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const float S = __builtin_fmaf(accp[i], accp[i], -m.kk[h]) - accu[i];
+            const float S = __builtin_fmaf(accp[i], accp[i], -accu[i]);
             bb = __builtin_amdgcn_alignbit(bb, __float_as_uint(S), 31);
         }
         hb[h] = bb;
