@@ -55,7 +55,7 @@ struct mrt_ctx {
     mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
     uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
     float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
-    uint32_t max_levels = mrt::kMaxLevels, top_target = 64;   // hierarchy depth rule (build_hierarchy)
+    uint32_t max_levels = mrt::kMaxLevels, top_target = 256;  // hierarchy depth rule (build_hierarchy)
     uint32_t levels = 1, n_nodes = 0, n_members = 0;
     uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
     uint32_t n_direct = 0, direct_first = 0;
@@ -495,7 +495,8 @@ uint16_t bf16_rne(float x) {
     return (uint16_t)(u >> 16);
 }
 float bf16_value(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
-void build_top_mfma(const std::vector<mrt::SphereRec>& top, std::vector<uint16_t>& out, double* max_c2, double* med_r2) {
+void build_top_mfma(const std::vector<mrt::SphereRec>& top, std::vector<uint16_t>& out, double* max_c2, double* med_r2,
+                    size_t* n_real) {
     const size_t tiles = top.size() / 32;
     out.assign(tiles * 512, 0);
     std::vector<double> r2s;
@@ -523,6 +524,7 @@ void build_top_mfma(const std::vector<mrt::SphereRec>& top, std::vector<uint16_t
             uint16_t* o = out.data() + t * 512;
             for (int k = 0; k < 16; k++) o[((k >> 3) * 32 + m) * 8 + (k & 7)] = kvals[k];
         }
+    *n_real = r2s.size();
     *med_r2 = 0.0;
     if (!r2s.empty()) { std::nth_element(r2s.begin(), r2s.begin() + r2s.size() / 2, r2s.end()); *med_r2 = r2s[r2s.size() / 2]; }
 }
@@ -821,13 +823,14 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     {
         std::vector<uint16_t> top_mfma;
         double max_c2 = 0.0, med_r2 = 0.0;
-        build_top_mfma(hier.top, top_mfma, &max_c2, &med_r2);
+        size_t n_real = 0;
+        build_top_mfma(hier.top, top_mfma, &max_c2, &med_r2, &n_real);
         HIP_TRY(c, upload((void**)&c->d_top_mfma, top_mfma.data(), top_mfma.size() * sizeof(uint16_t)));
         // The matrix-core sweep inflates R^2 by 2^-13 (o.o + C.C + R^2); rays start in or around the scene.
-        // Selected where that stays below about a tenth of the typical R^2; mrt_redraw checks the camera's
-        // own distance the same way.
+        // Selected where that stays below about a tenth of the typical R^2 (mrt_redraw checks the camera's
+        // own distance the same way) and there are enough records to fill most of a 32-record tile.
         c->mfma_r2_ref = med_r2;
-        c->mfma_scene_ok = med_r2 > 0.0 && kMfmaSlack * 2.0 * max_c2 <= 0.1 * med_r2;
+        c->mfma_scene_ok = n_real >= 24 && med_r2 > 0.0 && kMfmaSlack * 2.0 * max_c2 <= 0.1 * med_r2;
     }
     HIP_TRY(c, upload((void**)&c->d_member_index, hier.member_index.data(), hier.member_index.size() * sizeof(uint32_t)));
     // what shading a hit on sphere i reads, gathered per sphere (bit copies of the SoA entries)
