@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz: fp32 VALU lane-ops/s
 FLOP_PER_TEST = 23           # algorithmic flop per ray-sphere test (unfused count)
-VALU_PER_BOUND_TEST = 11     # as implemented: 10 fp32 VALU + 1 v_alignbit per cluster-bound test
+VALU_PER_BOUND_TEST = {1: 11, 2: 2}   # sweep variant 1: 10 fp32 VALU + 1 v_alignbit from SGPRs; 2: 1 fma + 1 v_alignbit after the matrix cores
 VALU_PER_MEMBER_TEST = 13    # 11 fp32 VALU + compare + queue bookkeeping per member discriminant
 
 WORKLOADS = {   # n_gpus -> (width, height, spp)
@@ -131,6 +131,7 @@ def main():
     st.set_world(spheres)
     if cam is not None:
         st.set_camera(cam)
+    sweep_variant = st.debug_sweep_variant() or 1
     _, _, lrows, _ = st.shard_info()
     staging = torch.empty((world, lrows, width, 4), dtype=torch.float32, device=device) if (use_dist and rank == 0) else None
 
@@ -214,12 +215,13 @@ def main():
                              "kernel ran (bound tests: the swept top level only)",
                      "algorithmic_sphere_tests_per_launch": tests_per_launch,
                      "algorithmic_tflops": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12, "peak_tflops": FP32_PEAK_TFLOPS,
+                     "sweep_variant": {1: "SGPR-fed VALU sweep", 2: "bf16-split GEMMs on the matrix cores (v_mfma_f32_32x32x16_bf16)"}[sweep_variant],
                      "mean_bounces_per_sample": hits / total_samples if total_samples else None,
                      "lane_utilisation": hits / lane_slots if lane_slots else None,
                      "executed_bound_tests_per_launch": hits / a.steps / world * c1["sweep_records"] if a.steps else 0.0,
                      "executed_member_discriminants_per_launch": member_tests / a.steps / world if a.steps else 0.0,
                      "executed_valu_issue_frac_of_sweep_and_members":
-                         ((hits * c1["sweep_records"] * VALU_PER_BOUND_TEST + member_tests * VALU_PER_MEMBER_TEST)
+                         ((hits * c1["sweep_records"] * VALU_PER_BOUND_TEST[sweep_variant] + member_tests * VALU_PER_MEMBER_TEST)
                           / max(1, a.steps) / world / kernel_s / LANE_OPS_PEAK) if a.steps else None},
         }
         if world == 1 and not a.no_cpu_baseline:

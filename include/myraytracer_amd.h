@@ -232,6 +232,8 @@ int mrt_debug_set_hierarchy(mrt_ctx* ctx, uint32_t max_levels, uint32_t top_targ
  * expanded test's slack is negligible for the scene and camera), 1 = SGPR-fed VALU sweep, 2 = matrix cores.
  * Either way the image is the same; takes effect at the next redraw. */
 int mrt_debug_set_sweep(mrt_ctx* ctx, int mode);
+/* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
+int mrt_debug_sweep_variant(mrt_ctx* ctx);
 /* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */
 int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);
 /* Diagnostic / tuning: pilot samples per pixel, waves per CU (0 = automatic).  Before the first

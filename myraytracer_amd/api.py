@@ -359,6 +359,10 @@ class State:
         """Tuning / test hook: 0 = automatic, 1 = SGPR-fed VALU sweep, 2 = matrix-core sweep (same image either way)."""
         self._check(self._L.mrt_debug_set_sweep(self._ctx, mode), "mrt_debug_set_sweep")
 
+    def debug_sweep_variant(self) -> int:
+        """1 = SGPR-fed VALU sweep, 2 = matrix-core sweep, for the next redraw (0 before a scene is set)."""
+        return int(self._L.mrt_debug_sweep_variant(self._ctx))
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._check(self._L.mrt_last_kernel_ms(self._ctx, C.byref(ms)), "mrt_last_kernel_ms")

@@ -477,6 +477,10 @@ void build_hierarchy(const float* centers4, const float* radii, uint32_t n, floa
     H.top.swap(cur);
 }
 
+// matrix-core sweep or SGPR-fed VALU sweep for the next launch: forced by mrt_debug_set_sweep,
+// else the scene's verdict (mrt_set_world_raw) and the same test on the camera's distance from the origin
+bool use_matrix_core_sweep(const mrt_ctx* c);
+
 // The top level once more, as the A operand of the matrix-core sweep (kernels.hip, mfma_sweep_tile): per
 // tile of 32 records 64 lanes x 8 bf16, lane l = row (l & 31), k = 8 (l >> 5) + j:
 //     k 0..2 C_hi, 3..5 C_hi, 6..8 C_lo, 9..11 (1,1,1), 12..14 Ck (hi, mid, lo), 15: 0
@@ -527,6 +531,14 @@ void build_top_mfma(const std::vector<mrt::SphereRec>& top, std::vector<uint16_t
     *n_real = r2s.size();
     *med_r2 = 0.0;
     if (!r2s.empty()) { std::nth_element(r2s.begin(), r2s.begin() + r2s.size() / 2, r2s.end()); *med_r2 = r2s[r2s.size() / 2]; }
+}
+
+bool use_matrix_core_sweep(const mrt_ctx* c) {
+    if (c->sweep_mode == 2) return true;
+    if (c->sweep_mode == 1 || !c->mfma_scene_ok) return false;
+    const float* o = c->cam_raw.origin;
+    const double o2 = c->cam_raw.mode ? (double)o[0] * o[0] + (double)o[1] * o[1] + (double)o[2] * o[2] : 0.0;
+    return kMfmaSlack * o2 <= 0.1 * c->mfma_r2_ref;
 }
 
 // wait for everything this context has in flight (caller's stream and both side streams)
@@ -952,10 +964,7 @@ int mrt_redraw(mrt_ctx* c) {
     p.n_padded = c->n_padded;
     { const uint32_t ch = (c->n_padded + mrt::kChunk - 1) / mrt::kChunk; p.mask_chunks = ch < 16u ? ch : 16u; }
     {
-        const double o2 = c->cam_raw.mode ? (double)c->cam_raw.origin[0] * c->cam_raw.origin[0] + (double)c->cam_raw.origin[1] * c->cam_raw.origin[1] +
-                                            (double)c->cam_raw.origin[2] * c->cam_raw.origin[2] : 0.0;
-        const bool cam_ok = kMfmaSlack * o2 <= 0.1 * c->mfma_r2_ref;
-        p.use_mfma = c->sweep_mode == 2 || (c->sweep_mode == 0 && c->mfma_scene_ok && cam_ok);
+        p.use_mfma = use_matrix_core_sweep(c) ? 1u : 0u;
     }
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
     p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records
@@ -1055,6 +1064,11 @@ int mrt_debug_set_sweep(mrt_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 2) return MRT_ERR_INVALID_ARG;
     c->sweep_mode = mode;
     return MRT_OK;
+}
+
+int mrt_debug_sweep_variant(mrt_ctx* c) {
+    if (!c || !c->have_world) return 0;
+    return use_matrix_core_sweep(c) ? 2 : 1;
 }
 
 int mrt_debug_set_hierarchy(mrt_ctx* c, uint32_t max_levels, uint32_t top_target) {
