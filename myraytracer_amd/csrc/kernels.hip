@@ -80,11 +80,17 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t z) {         // MurmurHash3 
     z ^= z >> 16; z *= 0x85EBCA6Bu; z ^= z >> 13; z *= 0xC2B2AE35u; z ^= z >> 16;
     return z;
 }
+// 2.0 * random_f32() - 1.0 (shader.wgsl:86) in one rounding: f32(i) * 2^-32 and the doubling are exact
+// (powers of two, no underflow), so the reference's value is fl(f32(i) * 2^-31 - 1) = this fma, bit for bit
+__device__ __forceinline__ float rng_pm1(Rng& r) {
+    r.draws++;
+    return __builtin_fmaf((float)rng_next(r), 0x1p-31f, -1.0f);
+}
 __device__ __forceinline__ V3 rng_unit_ball(Rng& r) {            // shader.wgsl:84-90
     V3 v;
     do {
-        float x = rng_f32(r); float y = rng_f32(r); float z = rng_f32(r);   // :77-82 order x,y,z
-        v = v3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
+        const float x = rng_pm1(r), y = rng_pm1(r), z = rng_pm1(r);          // :77-82 order x,y,z
+        v = v3(x, y, z);
     } while (dot3(v, v) > 1.0f);
     return v;
 }
@@ -498,8 +504,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     if (C->cam.defocus) {
                         float lx, ly;
                         do {                                                // unit disk by rejection
-                            float qx = rng_f32(rng); float qy = rng_f32(rng);
-                            lx = 2.0f * qx - 1.0f; ly = 2.0f * qy - 1.0f;
+                            lx = rng_pm1(rng); ly = rng_pm1(rng);
                         } while (__builtin_fmaf(ly, ly, lx * lx) > 1.0f);
                         V3 off = v3(lx * C->cam.ru[0] + ly * C->cam.rv[0],
                                     lx * C->cam.ru[1] + ly * C->cam.rv[1],
