@@ -398,7 +398,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     uint32_t base0 = 0, base1 = 0, base2 = 0, base3 = 0;     // CTR: the pixel's frame state, hashed per sample
     V3 color = v3(0.0f, 0.0f, 0.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, -1.0f), att = v3(1.0f, 1.0f, 1.0f);
-    uint32_t depth_left = 0, started = 0, bounces = 0, trips = 0;
+    uint32_t depth_left = 0, trips = 0;
+    unsigned long long started = 0, bounces = 0;     // wave totals, counted by ballot where the control flow is uniform
     unsigned long long mtests = 0;       // wave-uniform
 
 #ifdef MRT_STAMPS
@@ -474,6 +475,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         MRT_STAMP(5);
 
         const bool live = has_task && !task_done;
+        if (COUNT) started += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && need_sample));
         if (live) {
             pix_trips++;
             if (need_sample) {
@@ -517,7 +519,6 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 }
                 att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
                 depth_left = C->locals.ray_depth;
-                started++;
                 need_sample = false;
             }
         }
@@ -525,6 +526,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
 
         // ------------------------------------------------------------ world_hit, shader.wgsl:314-329
         const bool trace = live && depth_left != 0u;                        // lanes inside the loop of :339
+        if (COUNT) bounces += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(trace));
         float t_sup = 1.0e4f;                                               // :340
         int32_t best = -1;
         if (__any(trace)) {
@@ -790,7 +792,6 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             if (depth_left == 0u) {
                 path_done = true;                                           // loop :339 not entered -> :357
             } else {
-                bounces++;
                 if (best < 0) {
                     // color_sky, shader.wgsl:331-334, 343-345
                     float t = 0.5f * d.y + 0.5f;
@@ -878,13 +879,10 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     }
 
     if (COUNT && !PILOT) {
-        unsigned long long c0 = started, c1 = bounces, c2 = rng.draws;
+        const unsigned long long c0 = started, c1 = bounces;      // already wave totals
+        unsigned long long c2 = rng.draws;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            c0 += __shfl_xor(c0, off);
-            c1 += __shfl_xor(c1, off);
-            c2 += __shfl_xor(c2, off);
-        }
+        for (int off = 32; off > 0; off >>= 1) c2 += __shfl_xor(c2, off);
         if (lane == 0 && P.counters) {
             atomicAdd(P.counters + 0, c0);
             atomicAdd(P.counters + 1, c1);
