@@ -9,6 +9,8 @@ CLI      := $(LIBDIR)/native_runner
 # -ffp-contract=off: fma only where the source says fma (MRT-F32 rules).
 # -fno-vectorize -fno-slp-vectorize: v_pk_* fp32 is not faster than scalar VALU on gfx950
 # and SLP packing spends s_mov on SGPR pairs (profiles/r01_ubench_sphere_loop_*.txt).
+# -mllvm -amdgpu-mfma-vgpr-form: the matrix-core sweep reads its MFMA results with VALU ops; in AGPRs
+# every value would cost a v_accvgpr_read first.
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-vectorize -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wall -Wextra -Wno-unused-parameter
 SRCS     := $(CSRC)/kernels.hip $(CSRC)/tile_order.hip $(CSRC)/api.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
 HDRS     := $(CSRC)/mrt_internal.h include/myraytracer_amd.h
