@@ -50,6 +50,7 @@ struct mrt_ctx {
     uint16_t* d_top_mfma = nullptr;        // the top-level records as the MFMA A operand (build_top_mfma)
     bool mfma_scene_ok = false;            // the expanded test's extra slack is negligible for this scene
     double mfma_r2_ref = 0.0;              // median R^2 of the top level (camera check at launch)
+    float mfma_origin[3] = {0.0f, 0.0f, 0.0f};   // the matrix-core sweep works in coordinates relative to this point
     int sweep_mode = 0;                    // 0 automatic, 1 SGPR-fed VALU sweep, 2 matrix-core sweep (mrt_debug_set_sweep)
     float* d_shade = nullptr;              // 8 floats per sphere: centre, radius, material colour, fuzz | ior
     mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
@@ -499,32 +500,44 @@ uint16_t bf16_rne(float x) {
     return (uint16_t)(u >> 16);
 }
 float bf16_value(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
-void build_top_mfma(const std::vector<mrt::SphereRec>& top, std::vector<uint16_t>& out, double* max_c2, double* med_r2,
-                    size_t* n_real) {
+void build_top_mfma(const std::vector<mrt::SphereRec>& top, std::vector<uint16_t>& out, float origin[3], double* max_c2,
+                    double* med_r2, size_t* n_real) {
     const size_t tiles = top.size() / 32;
     out.assign(tiles * 512, 0);
     std::vector<double> r2s;
     *max_c2 = 0.0;
+    // the GEMMs run in coordinates relative to the centre of the records' bounding box (the slack grows with the
+    // squared distances from THAT point, wherever the scene sits); the kernel subtracts it from the ray origin
+    double lo[3] = {1e300, 1e300, 1e300}, hi3[3] = {-1e300, -1e300, -1e300};
+    for (const auto& r : top) {
+        if (!std::isfinite(r.neg_r2)) continue;
+        const double c[3] = {r.cx, r.cy, r.cz};
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], c[k]); hi3[k] = std::max(hi3[k], c[k]); }
+    }
+    for (int k = 0; k < 3; k++) origin[k] = lo[k] <= hi3[k] ? (float)(0.5 * (lo[k] + hi3[k])) : 0.0f;
     const uint16_t one = bf16_rne(1.0f);
     for (size_t t = 0; t < tiles; t++)
         for (uint32_t m = 0; m < 32; m++) {
             const mrt::SphereRec& r = top[32 * t + 16 * ((m >> 2) & 1u) + 4 * (m >> 3) + (m & 3u)];
             float ck = 3.0e38f;
+            // centre relative to the origin: exact in double, then rounded to f32 -- the rounding moves the bound by
+            // at most 2 eps |c|, which its radius absorbs
+            const float c[3] = {(float)((double)r.cx - origin[0]), (float)((double)r.cy - origin[1]), (float)((double)r.cz - origin[2])};
             if (std::isfinite(r.neg_r2)) {
-                const double c2 = (double)r.cx * r.cx + (double)r.cy * r.cy + (double)r.cz * r.cz, R2 = -(double)r.neg_r2;
+                const double c2 = (double)c[0] * c[0] + (double)c[1] * c[1] + (double)c[2] * c[2];
+                const double R = std::sqrt(-(double)r.neg_r2) + 2.0 * 0x1p-24 * std::sqrt(c2), R2 = R * R;
                 const double v = c2 - R2 - kMfmaSlack * (c2 + R2);
                 ck = (float)v;
                 if ((double)ck > v) ck = std::nextafterf(ck, -INFINITY);
                 *max_c2 = std::max(*max_c2, c2);
                 r2s.push_back(R2);
             }
-            const float c[3] = {r.cx, r.cy, r.cz};
-            uint16_t hi[3], lo[3];
-            for (int k = 0; k < 3; k++) { hi[k] = bf16_rne(c[k]); lo[k] = bf16_rne(c[k] - bf16_value(hi[k])); }
+            uint16_t hi[3], lo16[3];
+            for (int k = 0; k < 3; k++) { hi[k] = bf16_rne(c[k]); lo16[k] = bf16_rne(c[k] - bf16_value(hi[k])); }
             const uint16_t k0 = bf16_rne(ck);
             const float ck1 = ck - bf16_value(k0);
             const uint16_t k1 = bf16_rne(ck1), k2 = bf16_rne(ck1 - bf16_value(k1));
-            const uint16_t kvals[16] = {hi[0], hi[1], hi[2], hi[0], hi[1], hi[2], lo[0], lo[1], lo[2], one, one, one, k0, k1, k2, 0};
+            const uint16_t kvals[16] = {hi[0], hi[1], hi[2], hi[0], hi[1], hi[2], lo16[0], lo16[1], lo16[2], one, one, one, k0, k1, k2, 0};
             uint16_t* o = out.data() + t * 512;
             for (int k = 0; k < 16; k++) o[((k >> 3) * 32 + m) * 8 + (k & 7)] = kvals[k];
         }
@@ -536,8 +549,11 @@ void build_top_mfma(const std::vector<mrt::SphereRec>& top, std::vector<uint16_t
 bool use_matrix_core_sweep(const mrt_ctx* c) {
     if (c->sweep_mode == 2) return true;
     if (c->sweep_mode == 1 || !c->mfma_scene_ok) return false;
-    const float* o = c->cam_raw.origin;
-    const double o2 = c->cam_raw.mode ? (double)o[0] * o[0] + (double)o[1] * o[1] + (double)o[2] * o[2] : 0.0;
+    double o2 = 0.0;                              // squared distance of the camera from the GEMMs' origin
+    for (int k = 0; k < 3; k++) {
+        const double d = (c->cam_raw.mode ? (double)c->cam_raw.origin[k] : 0.0) - (double)c->mfma_origin[k];
+        o2 += d * d;
+    }
     return kMfmaSlack * o2 <= 0.1 * c->mfma_r2_ref;
 }
 
@@ -836,9 +852,10 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
         std::vector<uint16_t> top_mfma;
         double max_c2 = 0.0, med_r2 = 0.0;
         size_t n_real = 0;
-        build_top_mfma(hier.top, top_mfma, &max_c2, &med_r2, &n_real);
+        build_top_mfma(hier.top, top_mfma, c->mfma_origin, &max_c2, &med_r2, &n_real);
         HIP_TRY(c, upload((void**)&c->d_top_mfma, top_mfma.data(), top_mfma.size() * sizeof(uint16_t)));
-        // The matrix-core sweep inflates R^2 by 2^-13 (o.o + C.C + R^2); rays start in or around the scene.
+        // The matrix-core sweep inflates R^2 by 2^-13 (o.o + C.C + R^2), o and C relative to mfma_origin; rays
+        // start in or around the scene.
         // Selected where that stays below about a tenth of the typical R^2 (mrt_redraw checks the camera's
         // own distance the same way) and there are enough records to fill most of a 32-record tile.
         c->mfma_r2_ref = med_r2;
@@ -965,6 +982,7 @@ int mrt_redraw(mrt_ctx* c) {
     { const uint32_t ch = (c->n_padded + mrt::kChunk - 1) / mrt::kChunk; p.mask_chunks = ch < 16u ? ch : 16u; }
     {
         p.use_mfma = use_matrix_core_sweep(c) ? 1u : 0u;
+        for (int k = 0; k < 3; k++) p.mfma_origin[k] = c->mfma_origin[k];
     }
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
     p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records

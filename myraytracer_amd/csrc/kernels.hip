@@ -177,8 +177,10 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 // so ONE A operand per tile serves both, the second GEMM delivers U + o.o, and S is one fma of the two results.  What the split drops (C_lo v_lo and the remainders: 3 x 2^-18 of
 // every product) and the f32 accumulation err by at most 2.5e-5 o.o + 5e-5 C.C in S; the
 // test gives away 2^-13 = 1.2e-4 of o.o + C.C + R^2: o.o is scaled by kMfmaRaySlack here and the host
-// lowers Ck by 2^-13 (C.C + R^2) (api.cpp, build_top_mfma).  That is no longer scale-free: the host selects
-// this variant only where it is small against R^2; elsewhere the SGPR-fed sweep above runs.
+// lowers Ck by 2^-13 (C.C + R^2) (api.cpp, build_top_mfma).  o and C are taken relative to the centre of the
+// records' bounding box (P.mfma_origin; the rounding of o - origin is relative to the difference), so the
+// slack does not depend on where the scene sits, only on its extent against R: the host selects this
+// variant only where it is small against R^2; elsewhere the SGPR-fed sweep above runs.
 // Operand layout (lane l, r = l & 31, h = l >> 5): A[record r][k = 8h + j], B[k = 8h + j][ray r], j = 0..7;
 // result register i of lane l is record (i&3) + 8(i>>2) + 4h for ray r.  v_permlane32_swap(a, b) =
 // {(a.lo, b.lo), (a.hi, b.hi)} builds the B operands of both 32-ray halves from a lane's own k 0..7 and
@@ -571,7 +573,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
             // MFMA variant of the sweep: per-ray operands of the two GEMMs, rays x records (see mfma_sweep_tile)
             MfmaRay mr;
-            if (MFMA) mr = mfma_ray_operands(o, ds);
+            if (MFMA) mr = mfma_ray_operands(v3(o.x - P.mfma_origin[0], o.y - P.mfma_origin[1], o.z - P.mfma_origin[2]), ds);
             for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
                 const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
                 uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate

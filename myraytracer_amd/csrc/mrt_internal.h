@@ -49,6 +49,7 @@ struct KParams {
     // use_mfma selects that variant of the sweep (api.cpp decides per scene and camera)
     const uint16_t* top_mfma;
     uint32_t use_mfma;
+    float mfma_origin[3];       // the records of top_mfma are relative to this point (centre of their bounding box)
     const SphereRec* nodes;
     const uint32_t* member_index;
     uint32_t levels, n_nodes, n_members, gen_cap;

@@ -148,3 +148,32 @@ def test_both_sweep_variants_give_the_same_image(mrt, oracle, mode):
         same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
         assert same.all(), f"sweep mode {mode}, n={n}, offset {off}: " + mismatch_report(got, ref)
         assert c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
+
+
+def test_sweep_variant_choice_follows_extent_not_position(mrt, oracle):
+    """The matrix-core sweep works in coordinates relative to the scene's centre, so moving a scene 10,000 units
+    away keeps it (and the image stays bit-identical to the oracle); what switches to the SGPR-fed sweep is a
+    scene whose extent is large against its bounds: tight clumps of small spheres 1,000 units apart."""
+    sc, cam = mrt.scene_cover(1, True)
+    off = np.float32(10000.0)
+    far = sc.copy()
+    far["center"] += off
+    fcam = mrt.Camera(1, tuple(np.float32(v) + off for v in cam.lookfrom), tuple(np.float32(v) + off for v in cam.lookat),
+                      cam.vup, cam.vfov_deg, cam.defocus_angle_deg, cam.focus_dist)
+    ref = oracle_render(oracle, far, fcam, 64, 36, 2, 10, 5)
+    with mrt.State(mrt.Args(64, 36, 2, 10, 1.0), seed=5) as st:
+        st.set_world(far)
+        st.set_camera(fcam)
+        assert st.debug_sweep_variant() == 2
+        st.render(1)
+        got = st.read_framebuffer()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    rng = np.random.default_rng(9)
+    sparse = np.zeros(200, mrt.SPHERE_DTYPE)
+    for i in range(200):                 # 50 tight clumps of 4: bounds of radius ~0.2, 1,000 units apart
+        if i % 4 == 0:
+            clump = rng.uniform(-500, 500, 3)
+        sparse[i] = (tuple(clump + rng.uniform(-0.1, 0.1, 3)), 0.05, 1, (0.5, 0.5, 0.5), 0.0)
+    with mrt.State(mrt.Args(32, 18, 1, 4, 1.0), seed=5) as st:
+        st.set_world(sparse)
+        assert st.debug_sweep_variant() == 1
