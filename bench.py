@@ -216,6 +216,11 @@ def main():
                      "algorithmic_sphere_tests_per_launch": tests_per_launch,
                      "algorithmic_tflops": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12, "peak_tflops": FP32_PEAK_TFLOPS,
                      "sweep_variant": {1: "SGPR-fed VALU sweep", 2: "bf16-split GEMMs on the matrix cores (v_mfma_f32_32x32x16_bf16)"}[sweep_variant],
+                     # matrix-core work of the sweep: per wave and world_hit (sweep_records / 32) tiles x 2 ray halves x 2
+                     # GEMMs of v_mfma_f32_32x32x16_bf16 (32 x 32 x 16 x 2 flop each); dense bf16 peak 2,500 TFLOP/s
+                     "mfma_bf16_tflops": (lane_slots / 64.0 * (c1["sweep_records"] / 32.0) * 4.0 * 32768.0 / max(1, a.steps) / world
+                                          / kernel_s * 1e-12) if (a.steps and sweep_variant == 2) else 0.0,
+                     "mfma_bf16_peak_tflops": 2500.0,
                      "mean_bounces_per_sample": hits / total_samples if total_samples else None,
                      "lane_utilisation": hits / lane_slots if lane_slots else None,
                      "executed_bound_tests_per_launch": hits / a.steps / world * c1["sweep_records"] if a.steps else 0.0,
