@@ -232,6 +232,19 @@ int mrt_debug_set_hierarchy(mrt_ctx* ctx, uint32_t max_levels, uint32_t top_targ
  * expanded test's slack is negligible for the scene and camera), 1 = SGPR-fed VALU sweep, 2 = matrix cores.
  * Either way the image is the same; takes effect at the next redraw. */
 int mrt_debug_set_sweep(mrt_ctx* ctx, int mode);
+/* Diagnostic, host only (no context, no device): builds the bounding-sphere hierarchy that mrt_set_world would
+ * upload for these spheres and returns it for inspection (tests/test_host_logic.py checks its invariants):
+ *   top_out    n_top x (cx, cy, cz, -R^2)          the swept level, padded to a multiple of 32 with never-hit records
+ *   nodes_out  n_nodes x (cx, cy, cz, -R^2 | -r^2) levels 0 .. levels-1, level k at info[6 + k]
+ *   member_index_out  n_members sphere indices (level 0; padding slots hold 0 and a never-hit record)
+ *   mfma_out   n_top / 32 tiles x 512 bf16         the A operand of the matrix-core sweep, origin in mfma_origin_out
+ *   info[10] = {levels, n_top, n_nodes, n_members, n_direct, direct_first, level_base[0..3]}
+ * Any output pointer may be NULL (sizes are still returned in info); returns MRT_ERR_TOO_SMALL if a capacity
+ * (in records / indices / bf16 values) is insufficient. */
+int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_levels, uint32_t top_target,
+                              float* top_out, size_t top_cap, float* nodes_out, size_t nodes_cap,
+                              uint32_t* member_index_out, size_t member_cap, uint16_t* mfma_out, size_t mfma_cap,
+                              float mfma_origin_out[3], uint32_t info[10]);
 /* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
 int mrt_debug_sweep_variant(mrt_ctx* ctx);
 /* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */

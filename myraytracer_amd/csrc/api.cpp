@@ -1084,6 +1084,39 @@ int mrt_debug_set_sweep(mrt_ctx* c, int mode) {
     return MRT_OK;
 }
 
+int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_levels, uint32_t top_target,
+                              float* top_out, size_t top_cap, float* nodes_out, size_t nodes_cap,
+                              uint32_t* member_index_out, size_t member_cap, uint16_t* mfma_out, size_t mfma_cap,
+                              float mfma_origin_out[3], uint32_t info[10]) {
+    if ((!spheres && n) || !info || max_levels < 1 || max_levels > mrt::kMaxLevels || top_target < 1 || n > mrt::kMaxSpheres)
+        return MRT_ERR_INVALID_ARG;
+    std::vector<float> centers(4 * (n ? n : 1)), radii(n ? n : 1);
+    for (size_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) centers[4 * i + k] = spheres[i].center[k];
+        centers[4 * i + 3] = 1.0f;
+        radii[i] = spheres[i].radius;
+    }
+    Hierarchy h;
+    build_hierarchy(centers.data(), radii.data(), (uint32_t)n, 8.0f, max_levels, top_target, h);
+    std::vector<uint16_t> mf;
+    float origin[3];
+    double max_c2, med_r2;
+    size_t n_real;
+    build_top_mfma(h.top, mf, origin, &max_c2, &med_r2, &n_real);
+    info[0] = h.levels; info[1] = (uint32_t)h.top.size(); info[2] = (uint32_t)h.nodes.size(); info[3] = h.n_members;
+    info[4] = h.n_direct; info[5] = h.direct_first;
+    for (uint32_t k = 0; k < mrt::kMaxLevels; k++) info[6 + k] = h.level_base[k];
+    if ((top_out && top_cap < h.top.size()) || (nodes_out && nodes_cap < h.nodes.size()) ||
+        (member_index_out && member_cap < h.member_index.size()) || (mfma_out && mfma_cap < mf.size()))
+        return MRT_ERR_TOO_SMALL;
+    if (top_out) std::memcpy(top_out, h.top.data(), h.top.size() * sizeof(mrt::SphereRec));
+    if (nodes_out) std::memcpy(nodes_out, h.nodes.data(), h.nodes.size() * sizeof(mrt::SphereRec));
+    if (member_index_out) std::memcpy(member_index_out, h.member_index.data(), h.member_index.size() * sizeof(uint32_t));
+    if (mfma_out) std::memcpy(mfma_out, mf.data(), mf.size() * sizeof(uint16_t));
+    if (mfma_origin_out) for (int k = 0; k < 3; k++) mfma_origin_out[k] = origin[k];
+    return MRT_OK;
+}
+
 int mrt_debug_sweep_variant(mrt_ctx* c) {
     if (!c || !c->have_world) return 0;
     return use_matrix_core_sweep(c) ? 2 : 1;

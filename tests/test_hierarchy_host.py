@@ -1,0 +1,121 @@
+"""Host-side invariants of the bounding-sphere hierarchy and of the matrix-core operand it is re-expressed in
+(api.cpp build_clusters / build_hierarchy / build_top_mfma), checked without a GPU through
+mrt_debug_build_hierarchy.  These are the facts the conservativeness argument of DESIGN.md §4 rests on."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from myraytracer_amd import _lib
+
+INFLATE = 1.015          # mrt_internal.h kBoundInflate
+SLACK = 2.0 ** -13       # api.cpp kMfmaSlack
+
+
+def build(mrt, sc, max_levels=4, top_target=256):
+    L = _lib.load()
+    sc = np.ascontiguousarray(sc, mrt.SPHERE_DTYPE)
+    info = (C.c_uint32 * 10)()
+    assert L.mrt_debug_build_hierarchy(sc.ctypes.data, len(sc), max_levels, top_target, None, 0, None, 0, None, 0, None, 0, None, info) == 0
+    levels, n_top, n_nodes, n_members = info[0], info[1], info[2], info[3]
+    top = np.zeros((n_top, 4), np.float32)
+    nodes = np.zeros((n_nodes, 4), np.float32)
+    midx = np.zeros(n_members, np.uint32)
+    mf = np.zeros(n_top // 32 * 512, np.uint16)
+    org = (C.c_float * 3)()
+    assert L.mrt_debug_build_hierarchy(sc.ctypes.data, len(sc), max_levels, top_target, top.ctypes.data, len(top), nodes.ctypes.data,
+                                       len(nodes), midx.ctypes.data, len(midx), mf.ctypes.data, len(mf), org, info) == 0
+    return dict(levels=levels, top=top, nodes=nodes, midx=midx, mfma=mf, origin=np.array(list(org), np.float64),
+                n_direct=info[4], direct_first=info[5], level_base=[info[6 + k] for k in range(4)], n_members=n_members)
+
+
+def scenes(mrt):
+    rng = np.random.default_rng(77)
+    big = np.zeros(2300, mrt.SPHERE_DTYPE)
+    for i in range(len(big)):
+        big[i] = (tuple(rng.uniform(-30, 30, 3)), float(rng.uniform(0.05, 0.6)) * (-1 if i % 50 == 0 else 1), 1, (0.5, 0.5, 0.5), 0.0)
+    big[7] = ((0, -900, 0), 880.0, 1, (0.5, 0.5, 0.5), 0.0)
+    yield "default", mrt.scene_default()
+    yield "cover", mrt.scene_cover(1, True)[0]
+    yield "stress 40x40", mrt.scene_stress(3, 40)[0]
+    yield "random 2300", big
+    yield "single", mrt.scene_default()[:1]
+    yield "empty", np.zeros(0, mrt.SPHERE_DTYPE)
+
+
+def test_every_sphere_is_a_member_exactly_once_and_levels_are_well_formed(mrt):
+    for name, sc in scenes(mrt):
+        for max_levels, target in [(4, 256), (4, 1), (1, 64), (2, 8)]:
+            h = build(mrt, sc, max_levels, target)
+            never = np.isinf(h["nodes"][:h["n_members"], 3])
+            real = h["midx"][~never]
+            assert sorted(real.tolist()) == list(range(len(sc))), (name, max_levels, target)
+            # member records are bit copies of the spheres
+            c = np.asarray(sc["center"], np.float32).reshape(-1, 3)
+            r = np.asarray(sc["radius"], np.float32)
+            mem = h["nodes"][:h["n_members"]][~never]
+            assert np.array_equal(mem[:, :3], c[real]) and np.array_equal(mem[:, 3], -(r[real] * r[real])), name
+            assert len(h["top"]) % 32 == 0 and h["n_members"] % 4 == 0 and 1 <= h["levels"] <= max_levels
+            if len(sc) + 4 <= 1024:
+                assert h["levels"] == 1                                       # small scenes keep one level
+            bases = h["level_base"][:h["levels"]] + [len(h["nodes"])]
+            for k in range(h["levels"]):
+                assert (bases[k + 1] - bases[k]) % 4 == 0, (name, k)
+
+
+def test_every_bound_encloses_the_spheres_under_it_with_its_margin(mrt):
+    """node j of level k covers the members [j 4^k, (j+1) 4^k) of the hierarchy part of level 0; its radius must be
+    >= 1.015 x the farthest member surface measured from its (f32) centre -- at every level, and for the top."""
+    for name, sc in scenes(mrt):
+        if len(sc) == 0:
+            continue
+        for max_levels, target in [(4, 256), (4, 1), (2, 8)]:
+            h = build(mrt, sc, max_levels, target)
+            c = np.asarray(sc["center"], np.float64).reshape(-1, 3)
+            r = np.abs(np.asarray(sc["radius"], np.float64))
+            n_hier = h["direct_first"] if h["n_direct"] else h["n_members"]
+            never0 = np.isinf(h["nodes"][:n_hier, 3])
+            bases = h["level_base"][:h["levels"]] + [None]
+            for k in range(1, h["levels"] + 1):
+                recs = h["top"] if k == h["levels"] else h["nodes"][bases[k]:bases[k + 1] if k + 1 < h["levels"] else len(h["nodes"])]
+                span = 4 ** k
+                for j, rec in enumerate(recs):
+                    lo, hi = j * span, min(n_hier, (j + 1) * span)
+                    ids = h["midx"][lo:hi][~never0[lo:hi]] if lo < hi else np.zeros(0, np.uint32)
+                    if len(ids) == 0:
+                        assert np.isinf(rec[3]) and rec[3] > 0, (name, k, j)      # never-hit padding
+                        continue
+                    R = np.sqrt(-np.float64(rec[3]))
+                    far = (np.linalg.norm(c[ids] - rec[:3].astype(np.float64), axis=1) + r[ids]).max()
+                    assert R >= INFLATE * far * (1 - 1e-6), (name, max_levels, target, k, j, R, far)
+            # the direct spheres are the largest ones and sit outside every bound's bookkeeping
+            if h["n_direct"]:
+                d_ids = h["midx"][h["direct_first"]:h["direct_first"] + h["n_direct"]]
+                assert r[d_ids].min() > 8 * np.median(r)
+
+
+def bf16(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def test_matrix_core_operand_restates_the_top_level_with_its_slack(mrt):
+    """Per tile of 32 records the A operand holds C - origin split into bf16 hi + lo (twice the hi part), (1,1,1)
+    and Ck in three pieces, rows in MFMA result-register order; Ck must not exceed C.C - R^2 - 2^-13 (C.C + R^2)."""
+    for name, sc in scenes(mrt):
+        h = build(mrt, sc)
+        top, mf, org = h["top"], h["mfma"].reshape(-1, 2, 32, 8), h["origin"]
+        for t in range(len(top) // 32):
+            for m in range(32):
+                rec = top[32 * t + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)]
+                k = np.concatenate([mf[t, 0, m], mf[t, 1, m]])              # the row's 16 K slots
+                hi, hi2, lo, ones, ck3, pad = bf16(k[0:3]), bf16(k[3:6]), bf16(k[6:9]), bf16(k[9:12]), bf16(k[12:15]), k[15]
+                assert np.array_equal(hi, hi2) and np.array_equal(ones, [1.0, 1.0, 1.0]) and pad == 0
+                crel = (rec[:3].astype(np.float64) - org).astype(np.float32).astype(np.float64)
+                assert np.all(np.abs(hi + lo - crel) <= 2.0 ** -16 * np.abs(crel) + 1e-300), (name, t, m)
+                if np.isinf(rec[3]):
+                    assert ck3.sum() > 1e38                                   # never-hit: finite and huge
+                    continue
+                c2 = float(crel @ crel)
+                R2 = -float(rec[3])
+                assert ck3.sum() <= c2 - R2 - SLACK * (c2 + R2) + 1e-9 * (c2 + R2), (name, t, m)
+                assert ck3.sum() >= c2 - R2 - 1.01 * SLACK * (c2 + R2) - 1e-5 * (np.sqrt(c2 * R2) + R2), (name, t, m)
