@@ -159,16 +159,26 @@ def main():
     elapsed = time.perf_counter() - t0
     c1 = st.read_counters()
     kernel_ms = st.kernel_ms_history(min(a.steps, 64))
+    # multi-GPU numbers with and without the gather -- a second, separately timed run of the same
+    # K steps that only renders (reported as render_only_*, never as `value`)
+    elapsed_render_only = None
+    if use_dist:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            st.redraw()
+        fence()
+        elapsed_render_only = time.perf_counter() - t0
 
     # whole-job numbers: max time over ranks, summed counters
-    stats = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms))], dtype=torch.float64, device=device)
+    stats = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms)), elapsed_render_only or 0.0], dtype=torch.float64, device=device)
     sums = torch.tensor([c1["world_hit_calls"] - c0["world_hit_calls"], c1["samples"] - c0["samples"],
                          c1["lane_slots"] - c0["lane_slots"], c1["member_tests"] - c0["member_tests"]],
                         dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-    elapsed_max, kernel_ms_max = float(stats[0]), float(stats[1])
+    elapsed_max, kernel_ms_max, render_only_max = float(stats[0]), float(stats[1]), float(stats[2])
     hits, samples_counted, lane_slots, member_tests = (float(x) for x in sums)
 
     if rank == 0:
@@ -229,6 +239,10 @@ def main():
                          ((hits * c1["sweep_records"] * VALU_PER_BOUND_TEST[sweep_variant] + member_tests * VALU_PER_MEMBER_TEST)
                           / max(1, a.steps) / world / kernel_s / LANE_OPS_PEAK) if a.steps else None},
         }
+        if use_dist and render_only_max > 0:
+            out["render_only_value"] = total_samples / render_only_max * 1e-6
+            out["render_only_ms_per_step"] = render_only_max / max(1, a.steps) * 1e3
+            out["render_only_note"] = "the same K steps without the gather to rank 0, timed separately after the headline run"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spheres, cam, width, height, a.depth, seed)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
