@@ -174,7 +174,8 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 //     k  6..8   C_lo             . v_hi
 //     k  9..11  (1, 1, 1)        . (-o.ds | o.o (minus its slack)), each as hi, mid, lo
 //     k 12..14  Ck (hi, mid, lo) . (0, 0, 0 | 1, 1, 1)                 Ck = C.C - R^2 (minus its slack)
-// so ONE A operand per tile serves both, the second GEMM delivers U + o.o, and S is one fma of the two results.  What the split drops (C_lo v_lo and the remainders: 3 x 2^-18 of
+// so ONE A operand per tile serves both; the first GEMM's result, squared and negated, is the C input of the
+// second, which therefore delivers U + o.o - (oc.ds)^2 = -S: one multiply and one alignbit per (ray, record).  What the split drops (C_lo v_lo and the remainders: 3 x 2^-18 of
 // every product) and the f32 accumulation err by at most 2.5e-5 o.o + 5e-5 C.C in S; the
 // test gives away 2^-13 = 1.2e-4 of o.o + C.C + R^2: o.o is scaled by kMfmaRaySlack here and the host
 // lowers Ck by 2^-13 (C.C + R^2) (api.cpp, build_top_mfma).  o and C are taken relative to the centre of the
@@ -235,20 +236,20 @@ __device__ __forceinline__ void mfma_sweep_tile(const u32x4 a, const MfmaRay& m,
     uint32_t hb[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const f32x16 accp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m.bp[h]), zero, 0, 0, 0);
-        const f32x16 accu = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m.bu[h]), zero, 0, 0, 0);
+        // -(oc.ds)^2 becomes the C input of the second GEMM, which then delivers U + o.o - (oc.ds)^2 = -S in the
+        // same 16 registers (a true candidate has S > 0 by the margin of the slack, so the sign of -S decides)
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m.bp[h]), zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = -(acc[i] * acc[i]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m.bu[h]), acc, 0, 0, 0);
         uint32_t bb = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float S = __builtin_fmaf(accp[i], accp[i], -accu[i]);
-            bb = __builtin_amdgcn_alignbit(bb, __float_as_uint(S), 31);
-        }
+        for (int i = 0; i < 16; i++) bb = __builtin_amdgcn_alignbit(bb, __float_as_uint(acc[i]), 31);
         hb[h] = bb;
-        __builtin_amdgcn_sched_barrier(0);      // one half's 32 accumulator registers at a time
     }
     const auto r = __builtin_amdgcn_permlane32_swap(hb[0], hb[1], false, false);
-    mA = ~r[0] & 0xFFFFu;
-    mB = ~r[1] & 0xFFFFu;
+    mA = r[0] & 0xFFFFu;
+    mB = r[1] & 0xFFFFu;
 }
 
 // Candidate masks: per wave kBlockChunks x 64 lanes of u16 (one 16-sphere sign mask per chunk
