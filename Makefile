@@ -12,15 +12,28 @@ CLI      := $(LIBDIR)/native_runner
 # -mllvm -amdgpu-mfma-vgpr-form: the matrix-core sweep reads its MFMA results with VALU ops; in AGPRs
 # every value would cost a v_accvgpr_read first.
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-vectorize -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wall -Wextra -Wno-unused-parameter
-SRCS     := $(CSRC)/kernels.hip $(CSRC)/tile_order.hip $(CSRC)/api.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
-HDRS     := $(CSRC)/mrt_internal.h include/myraytracer_amd.h
+SRCS     := $(CSRC)/kernels.hip $(CSRC)/tile_order.hip $(CSRC)/api.cpp $(CSRC)/multi_gpu.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
+HDRS     := $(CSRC)/mrt_internal.h $(CSRC)/mrt_ctx.h include/myraytracer_amd.h
 
 all: $(LIB) $(CLI) oracle
 
-$(LIB): $(SRCS) $(HDRS) scripts/check_isa.py
-	@mkdir -p $(LIBDIR)
+# one object per source (build/ is git-ignored), so that touching the host code does not recompile the kernels
+OBJDIR   := build/obj
+OBJS     := $(patsubst $(CSRC)/%,$(OBJDIR)/%.o,$(SRCS))
+
+$(OBJDIR)/%.o: $(CSRC)/% $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c -o $@ $<
+
+# the ISA check (scalar-load hazards of the hand-issued s_loads) gates the link
+$(OBJDIR)/isa.ok: $(CSRC)/kernels.hip $(HDRS) scripts/check_isa.py
+	@mkdir -p $(OBJDIR)
 	python3 scripts/check_isa.py
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+	@touch $@
+
+$(LIB): $(OBJS) $(OBJDIR)/isa.ok
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS) -ldl
 
 $(CLI): $(CSRC)/native_runner.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/native_runner.cpp -L$(LIBDIR) -lmyraytracer_amd -Wl,-rpath,'$$ORIGIN'
@@ -29,7 +42,7 @@ oracle:
 	$(MAKE) -s -C oracle
 
 clean:
-	rm -rf $(LIBDIR)
+	rm -rf $(LIBDIR) $(OBJDIR)
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the render hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Started plainly with --gpus N > 1 it launches the N ranks itself (fresh child processes through
+torch.distributed.run, before this process has touched the GPU) and relays rank 0's JSON line.
 
 One "step" = one `State::redraw` (raytracer/src/lib.rs:241-307): a full raytrace pass of
 samples_per_frame spp over the whole image, blended into the accumulated framebuffer, and
@@ -15,6 +18,9 @@ Multi-GPU is weak scaling towards configs[3] (C4 = 8 x C3's samples at 8 GPUs): 
 and camera with N x C3's samples -- N=1 1920x1080x512, N=2 2716x1528x512 (2.001 x the pixels, same
 16:9 framing), N=4 3840x2160x512, N=8 3840x2160x1024 (= C4); the image is tile-sharded in
 interleaved 8-row bands, every rank renders (1/N) of it.
+
+--config c4 / c5 select BASELINE.json's configs[3] / configs[4] as they are stated (3840x2160x1024 cover
+scene; 1920x1080x4096 on the 10k-sphere stress scene): a fixed frame split over the N GPUs ("strong").
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM, as
 north_star asks; this path is VALU-bound so `valu` carries the binding fraction) and, at
@@ -31,18 +37,34 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz: fp32 VALU lane-ops/s
-FLOP_PER_TEST = 23           # algorithmic flop per ray-sphere test (unfused count)
 VALU_PER_BOUND_TEST = {1: 11, 2: 2}   # sweep variant 1: 10 fp32 VALU + 1 v_alignbit from SGPRs; 2: 1 fma + 1 v_alignbit after the matrix cores
 VALU_PER_MEMBER_TEST = 13    # 11 fp32 VALU + compare + queue bookkeeping per member discriminant
 
-WORKLOADS = {   # n_gpus -> (width, height, spp)
+WORKLOADS = {   # config c3 (default), weak scaling towards C4: n_gpus -> (width, height, spp)
     1: (1920, 1080, 512),
     2: (2716, 1528, 512),
     4: (3840, 2160, 512),
     8: (3840, 2160, 1024),
 }
+FIXED_CONFIGS = {   # BASELINE.json configs[3] / configs[4] as stated, whatever N: (scene, width, height, spp)
+    "c4": ("cover-glass", 3840, 2160, 1024),
+    "c5": ("stress", 1920, 1080, 4096),
+}
+
+
+def launch_ranks(n, argv):
+    """--gpus N without a launcher: start the N ranks as fresh children (this process has not touched the GPU and
+    never will), relay their output -- rank 0 prints the JSON line -- and exit with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def host_cores():
@@ -78,6 +100,11 @@ def cpu_baseline(spheres, cam, width, height, depth, seed, budget_s=15.0):
                       f"OpenMP over rows), {dt:.1f} s; rate is spp-independent, so no extrapolation is applied"}
 
 
+def tests_per_launch(hits, steps, world, n_spheres):
+    """What the reference's linear scan (shader.wgsl:314-329: one sphere test per sphere per world_hit) executes per launch."""
+    return hits / steps / world * n_spheres if steps else 0.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,8 +115,13 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--scene", default="cover-glass", choices=["cover-glass", "cover", "default", "stress"])
+    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"],
+                    help="c3 (default): the headline 1920x1080x512 cover scene, weak-scaled with N; c4 / c5: BASELINE configs[3] / [4] as stated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+    force_dist = os.environ.get("MRT_BENCH_FORCE_DIST") == "1"      # rehearses the RCCL path on one GPU
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or force_dist):
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -108,12 +140,17 @@ def main():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or os.environ.get("MRT_BENCH_FORCE_DIST") == "1"   # the env var rehearses the RCCL path on one GPU
+    use_dist = world > 1 or force_dist
     if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     width, height, spp = WORKLOADS.get(a.gpus, WORKLOADS[1])
-    headline = not (a.width or a.height or a.spp) and a.scene == "cover-glass" and a.depth == 50 and a.gpus in WORKLOADS
+    scaling = "weak"
+    if a.config in FIXED_CONFIGS:
+        a.scene, width, height, spp = FIXED_CONFIGS[a.config]
+        scaling = "strong"
+    headline = (not (a.width or a.height or a.spp) and a.depth == 50 and
+                ((a.config == "c3" and a.scene == "cover-glass" and a.gpus in WORKLOADS) or a.config in FIXED_CONFIGS))
     width, height, spp = a.width or width, a.height or height, a.spp or spp
     seed = 1
     if a.scene == "cover-glass":
@@ -147,7 +184,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(a.warmup):
+    # Frame 0 of a fresh context (shuffle [0;4], lib.rs:422) is the frame whose whole-frame ORACLE counters are committed
+    # in tests/golden/fullsize_rows.json (C3): when this run renders that workload, its first frame must reproduce them
+    first_frame_check = None
+    golden = None
+    if world == 1 and headline and a.config == "c3" and a.warmup > 0:      # (the checked frame is the first warm-up step)
+        try:
+            golden = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_rows.json")))["configs"]["c3"]["frame0_counters"]
+        except Exception:
+            golden = None
+    done_first = False
+    if golden is not None:
+        step()
+        fence()
+        cf = st.read_counters()
+        first_frame_check = all(cf[k] == golden[k] for k in ("samples", "world_hit_calls", "rng_draws"))
+        assert first_frame_check, (cf, golden)
+        done_first = True
+    for _ in range(a.warmup - (1 if done_first else 0)):
         step()
     fence()
     c0 = st.read_counters()
@@ -181,6 +235,14 @@ def main():
     elapsed_max, kernel_ms_max, render_only_max = float(stats[0]), float(stats[1]), float(stats[2])
     hits, samples_counted, lane_slots, member_tests = (float(x) for x in sums)
 
+    # which ranks RCCL actually connected: every rank reports its device; the root checks the communicator's size
+    rank_devices = [None] * world
+    if use_dist:
+        dist.all_gather_object(rank_devices, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(device),
+                                              "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None)})
+    else:
+        rank_devices = [{"rank": 0, "local_rank": local_rank, "device": torch.cuda.get_device_name(device)}]
+
     if rank == 0:
         total_samples = float(width) * height * spp * a.steps
         assert samples_counted == total_samples or a.steps == 0, (samples_counted, total_samples)
@@ -192,39 +254,48 @@ def main():
         # with the previous framebuffer -- 48 B per pixel -- is finalize_kernel, an HBM-bound ~25 us pass.)
         alg_bytes = local_px * (16 + 16) + ((n_spheres + 7) // 8 * 8) * 16 + n_spheres * 28
         achieved = alg_bytes / (kernel_ms_max * 1e-3) * 1e-9
-        traffic = None
+        key = f"{a.scene}_{width}x{height}x{spp}_n{world}"
+        traffic, pmc = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            traffic = tj.get(f"{a.scene}_{width}x{height}x{spp}_n{world}")
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(key)
         except Exception:
             pass
-        tests_per_launch = hits / a.steps / world * n_spheres if a.steps else 0.0
-        # consecutive frames' render kernels overlap (two frames in flight), so a kernel's own duration
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "valu_pmc.json"))).get(key)
+        except Exception:
+            pass
+        # consecutive frames' render kernels overlap (frames in flight), so a kernel's own duration
         # (roofline.kernel_ms) exceeds the wall time per step; the VALU fractions use the wall time
         kernel_s = elapsed_max / max(1, a.steps)
+        scene_names = {"cover-glass": "RTIOW cover scene with Dielectric + defocus blur", "cover": "RTIOW cover scene (Lambertian + Metal)",
+                       "stress": "10k-sphere stress scene (100 x 100 jittered grid + ground, 80/15/5 % L/M/D)",
+                       "default": "the reference's shipped 4-sphere scene"}
         out = {
             "metric": "Msamples/s (pixels x spp / s), random-spheres",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed_max / max(1, a.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed_max / max(1, a.steps) * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"RTIOW cover scene ({n_spheres} spheres, scene_seed 1) "
-                                   f"{'with Dielectric + defocus blur' if a.scene == 'cover-glass' else a.scene}, "
+            "config": {"workload": f"{a.config.upper() if headline else 'custom'}: {scene_names[a.scene]} ({n_spheres} spheres, scene_seed 1), "
                                    f"{width}x{height}, {spp} spp per frame, depth {a.depth}, seed {seed}; "
                                    f"1 step = 1 redraw (+ RCCL gather to rank 0 when n_gpus > 1)",
                        "headline": headline, "sharding": f"interleaved 8-row bands over {world} GPU(s)"},
+            "rccl_world_size": dist.get_world_size() if use_dist else 1,
+            "ranks": rank_devices,
+            "scene_upload_ms": st.last_set_world_ms(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/hbm_traffic.json: rocprofv3 --pmc passes of this command (profiles/README.md), "
+                                           "NOT measured in this run" if traffic is not None else None,
                          "kernel": "mrt::render_kernel", "kernel_ms": kernel_ms_max,
                          "note": "kernel_ms = mean launch duration (HIP events on its stream); launches of consecutive "
                                  "frames overlap, so it is longer than ms_per_step",
                          "algorithmic_bytes_per_launch": alg_bytes},
-            "valu": {"note": "the binding resource is VALU issue.  `algorithmic_*` = what the reference's linear scan "
-                             "(one test per sphere per world_hit, 23 flop each) would execute; the kernel sweeps the top level "
-                             "of a bounding-sphere hierarchy and evaluates member discriminants only under candidate bounds, so "
-                             "the algorithmic rate may exceed the executed one and the fp32 peak; `executed_*` is what the "
-                             "kernel ran (bound tests: the swept top level only)",
-                     "algorithmic_sphere_tests_per_launch": tests_per_launch,
-                     "algorithmic_tflops": tests_per_launch * FLOP_PER_TEST / kernel_s * 1e-12, "peak_tflops": FP32_PEAK_TFLOPS,
+            "valu": {"note": "the binding resource is VALU issue, not HBM.  `executed_*` is what the kernel ran per launch (bound tests: "
+                             "the swept top level of the bounding-sphere hierarchy; member discriminants only under candidate "
+                             "bounds); `pmc_*` are SQ counters of a rocprofv3 --pmc pass of this command (profiles/valu_pmc.json, "
+                             "NOT measured in this run): issue_frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles), "
+                             "thread_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)",
+                     "reference_sphere_tests_per_launch": tests_per_launch(hits, a.steps, world, n_spheres),
                      "sweep_variant": {1: "SGPR-fed VALU sweep", 2: "bf16-split GEMMs on the matrix cores (v_mfma_f32_32x32x16_bf16)"}[sweep_variant],
                      # matrix-core work of the sweep: per wave and world_hit (sweep_records / 32) tiles x 2 ray halves x 2
                      # GEMMs of v_mfma_f32_32x32x16_bf16 (32 x 32 x 16 x 2 flop each); dense bf16 peak 2,500 TFLOP/s
@@ -237,8 +308,13 @@ def main():
                      "executed_member_discriminants_per_launch": member_tests / a.steps / world if a.steps else 0.0,
                      "executed_valu_issue_frac_of_sweep_and_members":
                          ((hits * c1["sweep_records"] * VALU_PER_BOUND_TEST[sweep_variant] + member_tests * VALU_PER_MEMBER_TEST)
-                          / max(1, a.steps) / world / kernel_s / LANE_OPS_PEAK) if a.steps else None},
+                          / max(1, a.steps) / world / kernel_s / LANE_OPS_PEAK) if a.steps else None,
+                     "pmc_issue_frac": pmc.get("issue_frac") if pmc else None,
+                     "pmc_thread_utilisation": pmc.get("thread_utilisation") if pmc else None,
+                     "pmc_valu_insts_per_wave_bounce": pmc.get("valu_insts_per_wave_bounce") if pmc else None},
         }
+        if first_frame_check is not None:
+            out["first_frame_counters_equal_oracle"] = first_frame_check
         if use_dist and render_only_max > 0:
             out["render_only_value"] = total_samples / render_only_max * 1e-6
             out["render_only_ms_per_step"] = render_only_max / max(1, a.steps) * 1e3

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 1
+#define MRT_ABI_VERSION 2
 
 typedef enum {
     MRT_OK = 0,
@@ -153,9 +153,13 @@ int mrt_set_stream(mrt_ctx* ctx, void* hip_stream);
 /* ------------------------------------------------------------------ scene */
 
 /* Object::new's upload (lib.rs:768-863): the raw::World index block and the three SoA
- * arrays, verbatim.  vec4_data: n_vec4 x 4 floats, f32_data: n_f32 floats, i32_data:
- * n_i32 ints.  All base+length ranges are validated. */
-int mrt_set_world_raw(mrt_ctx* ctx, const mrt_world* world,
+ * arrays, verbatim.  `world` points to world_bytes bytes: MRT_WORLD_BYTES_REFERENCE (64) = the
+ * reference's raw::World exactly as lib.rs:676-684 lays it out (no dielectrics), or
+ * sizeof(mrt_world) (80) = with the DielectricRange extension; nothing beyond world_bytes is
+ * read.  vec4_data: n_vec4 x 4 floats, f32_data: n_f32 floats, i32_data: n_i32 ints.  All
+ * base+length ranges are validated. */
+#define MRT_WORLD_BYTES_REFERENCE 64
+int mrt_set_world_raw(mrt_ctx* ctx, const void* world, size_t world_bytes,
                       const float* vec4_data, size_t n_vec4,
                       const float* f32_data, size_t n_f32,
                       const int32_t* i32_data, size_t n_i32);
@@ -217,6 +221,33 @@ void* mrt_framebuffer_device_ptr(mrt_ctx* ctx);
  * world  > 1: this shard's packed rows, local_rows*width*4 floats. */
 int mrt_read_framebuffer(mrt_ctx* ctx, float* rgba_out, size_t cap_floats);
 int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since create/reset */
+
+/* ------------------------------------------------------------------ multi-GPU (no reference counterpart)
+ *
+ * The reference drives one adapter (lib.rs:329-335).  The caller that owns its frame loop (State::new /
+ * State::redraw, lib.rs:217-234, :241-307) uses N GPUs by holding one mrt_ctx per GPU, ctxs[i] created on
+ * device i with mrt_set_shard(ctxs[i], i, N), calling mrt_redraw on each and then ONE gather per frame. */
+
+/* One process, N contexts.  Copies every shard's most recent framebuffer into its interleaved place in the
+ * root's full-frame buffer: one strided device-to-device (peer-to-peer over xGMI) copy per shard, issued on
+ * that shard's own stream (so it follows its redraw), all links at once; the root's stream then waits for all
+ * of them.  Asynchronous; read the result with mrt_read_gathered / mrt_gathered_device_ptr on ctxs[root].
+ * Requires ctxs[i] to be shard i of n of the same width x height. */
+int mrt_gather(mrt_ctx* const* ctxs, uint32_t n, uint32_t root);
+/* One process per GPU (shard rank = RCCL rank): grouped ncclSend / ncclRecv of the packed bands on
+ * `nccl_comm` (an ncclComm_t the caller created with ITS librccl; this library resolves RCCL's entry points at
+ * run time and does not link it), one message per peer straight to the root, then the un-permute on the
+ * root, all on the ctx's stream.  Collective: every rank calls it once per frame. */
+int mrt_gather_rccl(mrt_ctx* ctx, void* nccl_comm, uint32_t root);
+/* Full frame on the root after a gather: height*width*4 floats, row 0 = bottom (device pointer valid until the
+ * next gather on this ctx; order further work after the ctx's stream). */
+void* mrt_gathered_device_ptr(mrt_ctx* root_ctx);
+int mrt_read_gathered(mrt_ctx* root_ctx, float* rgba_out, size_t cap_floats);   /* synchronises */
+/* host-only index math of the interleave: local row r of shard (rank, world) is this global row; rows per
+ * shard; and the un-permute of a rank-major [world][local_rows][width][4] array into [height][width][4] */
+uint32_t mrt_shard_global_row(uint32_t local_row, uint32_t rank, uint32_t world);
+uint32_t mrt_shard_local_rows(uint32_t height, uint32_t world);
+int mrt_unshard_rows(const float* gathered, uint32_t world, uint32_t width, uint32_t height, float* out);
 /* Diagnostic: the 16 raw u64 counter slots  (0..4 = mrt_counters; 6.. are phase cycle sums
  * written only by the -DMRT_STAMPS profiling build). */
 int mrt_debug_read_counters(mrt_ctx* ctx, uint64_t out[16]);
@@ -255,6 +286,9 @@ int mrt_debug_set_schedule(mrt_ctx* ctx, uint32_t pilot_spp, int waves_per_cu);
 /* Diagnostic: per-wave log {t_start, t_end (100 MHz ticks), loop trips, bounces}, 4 u64 per 8x8
  * persistent wave, written only by the -DMRT_STAMPS build.  out == NULL allocates the log. */
 int mrt_debug_wave_log(mrt_ctx* ctx, uint64_t* out, size_t cap_waves, size_t* n_waves);
+/* Host wall time (ms) the most recent mrt_set_world* call spent building and uploading the bounding-sphere
+ * hierarchy (a one-off per scene, outside the per-frame metric). */
+int mrt_debug_last_set_world_ms(mrt_ctx* ctx, float* ms);
 /* Elapsed GPU time (ms) of the most recent redraw's render kernel, from HIP events on
  * the launch stream.  Synchronises on the stop event. */
 int mrt_last_kernel_ms(mrt_ctx* ctx, float* ms);
@@ -298,10 +332,13 @@ int mrt_scene_load(const char* path, mrt_sphere* out, size_t cap, mrt_camera* ca
 /* ------------------------------------------------------------------ image output (host only) */
 
 /* rgba: height*width*4 floats, row 0 = bottom (as read back).  PFM keeps linear floats
- * (bottom-up is PFM's native order); PPM applies gamma 2.0 (sqrt) and flips to top-down,
- * which is what the reference's present pass + sRGB surface approximates on screen. */
+ * (bottom-up is PFM's native order).  PPM is what the reference's present pass puts on screen: the
+ * linear value (sample_framebuffer.wgsl:38-41) stored to the sRGB surface (lib.rs:349-351, :1133), i.e.
+ * clamp to [0,1], the sRGB OETF (12.92 c below 0.0031308, else 1.055 c^(1/2.4) - 0.055), round to 8 bits,
+ * rows flipped to top-down (sample_framebuffer.wgsl:24). */
 int mrt_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height);
 int mrt_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height);
+uint8_t mrt_srgb8(float linear);      /* the per-channel conversion mrt_write_ppm applies */
 
 #ifdef __cplusplus
 }

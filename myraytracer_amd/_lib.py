@@ -22,6 +22,8 @@ EXPORTS = [
     "mrt_kernel_ms_history", "mrt_debug_read_counters", "mrt_debug_wave_log", "mrt_debug_set_tile_sort", "mrt_debug_set_cluster_factor", "mrt_debug_set_hierarchy", "mrt_debug_set_sweep", "mrt_debug_sweep_variant", "mrt_debug_build_hierarchy", "mrt_debug_read_pixel_costs", "mrt_debug_set_schedule",
     "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_scene_default", "mrt_scene_cover",
     "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
+    "mrt_srgb8", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
+    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms",
 ]
 
 
@@ -104,7 +106,7 @@ def load():
         "mrt_destroy": (None, [vp]),
         "mrt_set_shard": (i32, [vp, u32, u32]),
         "mrt_set_stream": (i32, [vp, vp]),
-        "mrt_set_world_raw": (i32, [vp, P(MrtWorld), vp, sz, vp, sz, vp, sz]),
+        "mrt_set_world_raw": (i32, [vp, vp, sz, vp, sz, vp, sz, vp, sz]),
         "mrt_set_world": (i32, [vp, vp, sz]),
         "mrt_pack_world": (i32, [vp, sz, P(MrtWorld), vp, sz, P(sz), vp, sz, P(sz), vp, sz, P(sz)]),
         "mrt_set_camera": (i32, [vp, P(MrtCamera)]),
@@ -149,6 +151,15 @@ def load():
         "mrt_scene_load": (i32, [C.c_char_p, vp, sz, P(MrtCamera), P(C.c_int)]),
         "mrt_write_pfm": (i32, [C.c_char_p, vp, u32, u32]),
         "mrt_write_ppm": (i32, [C.c_char_p, vp, u32, u32]),
+        "mrt_srgb8": (C.c_uint8, [f32]),
+        "mrt_gather": (i32, [P(vp), u32, u32]),
+        "mrt_gather_rccl": (i32, [vp, vp, u32]),
+        "mrt_gathered_device_ptr": (vp, [vp]),
+        "mrt_read_gathered": (i32, [vp, vp, sz]),
+        "mrt_shard_global_row": (u32, [u32, u32, u32]),
+        "mrt_shard_local_rows": (u32, [u32, u32]),
+        "mrt_unshard_rows": (i32, [vp, u32, u32, u32, vp]),
+        "mrt_debug_last_set_world_ms": (i32, [vp, P(f32)]),
     }
     assert sorted(sig) == sorted(EXPORTS)
     for name, (res, args) in sig.items():

@@ -209,7 +209,7 @@ def load_scene(path: str):
 
 
 def write_image(path: str, rgba: np.ndarray):
-    """rgba: (H, W, 4) f32, row 0 = bottom.  .ppm -> 8-bit gamma-2, anything else -> PFM."""
+    """rgba: (H, W, 4) f32, row 0 = bottom.  .ppm -> 8-bit sRGB (what the reference's surface shows), anything else -> PFM."""
     rgba = np.ascontiguousarray(rgba, np.float32)
     h, w, _ = rgba.shape
     fn = _lib.load().mrt_write_ppm if path.endswith(".ppm") else _lib.load().mrt_write_pfm
@@ -266,11 +266,13 @@ class State:
         arr = world.to_array() if isinstance(world, World) else np.ascontiguousarray(world, SPHERE_DTYPE)
         self._check(self._L.mrt_set_world(self._ctx, arr.ctypes.data, len(arr)), "mrt_set_world")
 
-    def set_world_raw(self, w: MrtWorld, vec4: np.ndarray, f32: np.ndarray, i32: np.ndarray):
+    def set_world_raw(self, w, vec4: np.ndarray, f32: np.ndarray, i32: np.ndarray):
+        """w: an MrtWorld (80 bytes) or any buffer holding the reference's 64-byte raw::World."""
+        wbuf = bytes(w) if not isinstance(w, (bytes, bytearray)) else bytes(w)
         vec4 = np.ascontiguousarray(vec4, np.float32).reshape(-1, 4)
         f32 = np.ascontiguousarray(f32, np.float32)
         i32 = np.ascontiguousarray(i32, np.int32)
-        self._check(self._L.mrt_set_world_raw(self._ctx, C.byref(w), vec4.ctypes.data, len(vec4), f32.ctypes.data,
+        self._check(self._L.mrt_set_world_raw(self._ctx, wbuf, len(wbuf), vec4.ctypes.data, len(vec4), f32.ctypes.data,
                                               len(f32), i32.ctypes.data, len(i32)), "mrt_set_world_raw")
 
     def set_camera(self, cam: Camera):
@@ -367,3 +369,59 @@ class State:
         ms = C.c_float()
         self._check(self._L.mrt_last_kernel_ms(self._ctx, C.byref(ms)), "mrt_last_kernel_ms")
         return float(ms.value)
+
+    def debug_read_pixel_costs(self) -> np.ndarray:
+        """(rows, W) u32: bounce-loop trips (= world_hit calls when ray_depth > 0) of every pixel in the last frame;
+        full image when unsharded, else this shard's packed rows."""
+        _, world, rows, width = self.shard_info()
+        packed = np.empty((rows, width), np.uint32)
+        self._check(self._L.mrt_debug_read_pixel_costs(self._ctx, packed.ctypes.data, packed.size), "mrt_debug_read_pixel_costs")
+        return packed[:self.args.height] if world == 1 else packed
+
+    def last_set_world_ms(self) -> float:
+        """Host wall time of the last scene upload (hierarchy build + copies); one-off per scene."""
+        ms = C.c_float()
+        self._check(self._L.mrt_debug_last_set_world_ms(self._ctx, C.byref(ms)), "mrt_debug_last_set_world_ms")
+        return float(ms.value)
+
+    # -- multi-GPU (one process per GPU): RCCL gather on a caller-supplied ncclComm_t
+    def gather_rccl(self, nccl_comm: int, root: int = 0):
+        self._check(self._L.mrt_gather_rccl(self._ctx, nccl_comm, root), "mrt_gather_rccl")
+
+    def gathered_device_ptr(self) -> int:
+        return int(self._L.mrt_gathered_device_ptr(self._ctx) or 0)
+
+    def read_gathered(self) -> np.ndarray:
+        """(H, W, 4) f32, row 0 = bottom: the full frame assembled on this (root) State by the last gather."""
+        out = np.empty((self.args.height, self.args.width, 4), np.float32)
+        self._check(self._L.mrt_read_gathered(self._ctx, out.ctypes.data, out.size), "mrt_read_gathered")
+        return out
+
+
+def gather(states: Sequence[State], root: int = 0):
+    """mrt_gather: one process, len(states) contexts (states[i] = shard i of n); the full frame lands on states[root]."""
+    L = _lib.load()
+    arr = (C.c_void_p * len(states))(*[s._ctx for s in states])
+    st = L.mrt_gather(arr, len(states), root)
+    if st:
+        raise MrtError(st, "mrt_gather", (L.mrt_last_error(states[root]._ctx) or L.mrt_last_error(None)).decode())
+
+
+def shard_global_row(local_row: int, rank: int, world: int) -> int:
+    return int(_lib.load().mrt_shard_global_row(local_row, rank, world))
+
+
+def shard_local_rows(height: int, world: int) -> int:
+    return int(_lib.load().mrt_shard_local_rows(height, world))
+
+
+def unshard_rows(gathered: np.ndarray, height: int) -> np.ndarray:
+    """Host un-permute (mrt_unshard_rows): [world, local_rows, W, 4] rank-major -> [height, W, 4]."""
+    gathered = np.ascontiguousarray(gathered, np.float32)
+    world, lrows, width, _ = gathered.shape
+    assert lrows == shard_local_rows(height, world)
+    out = np.zeros((height, width, 4), np.float32)
+    st = _lib.load().mrt_unshard_rows(gathered.ctypes.data, world, width, height, out.ctypes.data)
+    if st:
+        raise MrtError(st, "mrt_unshard_rows")
+    return out

@@ -13,99 +13,33 @@
 #include <array>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "mrt_internal.h"
+#include "mrt_ctx.h"
 
 static_assert(sizeof(mrt_args) == 20, "mrt_args layout");
 static_assert(sizeof(mrt_locals) == 48, "Locals is 48 bytes (lib.rs:368-377)");
 static_assert(sizeof(mrt_world) == 80, "raw::World 64 B + DielectricRange 16 B");
+static_assert(offsetof(mrt_world, dielectrics) == MRT_WORLD_BYTES_REFERENCE, "raw::World is the first 64 bytes of mrt_world");
 static_assert(sizeof(mrt_sphere) == 36, "mrt_sphere layout");
 static_assert(sizeof(mrt_camera) == 52, "mrt_camera layout");
 static_assert(sizeof(mrt_camera_raw) == 80, "mrt_camera_raw layout");
 static_assert(sizeof(mrt::SphereRec) == 16, "SphereRec layout");
 
-struct mrt_ctx {
-    int device = 0;
-    mrt_args args{};
-    uint64_t seed = 0;
-    mrt_locals locals{};
-    uint32_t frames_done = 0;          // State::sample_count (lib.rs:213, 300)
-
-    uint32_t shard_rank = 0, shard_world = 1;
-    uint32_t local_bands = 0;
-
-    mrt_world world{};
-    bool have_world = false;
-    uint32_t n_spheres = 0, n_padded = 0;
-    mrt_camera_raw cam_raw{};
-
-    // device memory (all owned)
-    mrt::SphereRec* d_spheres = nullptr;
-    mrt::SphereRec* d_clusters = nullptr;  // bounding spheres the sweep tests (up to kClusterK spheres each)
-    uint16_t* d_top_mfma = nullptr;        // the top-level records as the MFMA A operand (build_top_mfma)
-    bool mfma_scene_ok = false;            // the expanded test's extra slack is negligible for this scene
-    double mfma_r2_ref = 0.0;              // median R^2 of the top level (camera check at launch)
-    float mfma_origin[3] = {0.0f, 0.0f, 0.0f};   // the matrix-core sweep works in coordinates relative to this point
-    int sweep_mode = 0;                    // 0 automatic, 1 SGPR-fed VALU sweep, 2 matrix-core sweep (mrt_debug_set_sweep)
-    float* d_shade = nullptr;              // 8 floats per sphere: centre, radius, material colour, fuzz | ior
-    mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
-    uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
-    float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
-    uint32_t max_levels = mrt::kMaxLevels, top_target = 256;  // hierarchy depth rule (build_hierarchy)
-    uint32_t levels = 1, n_nodes = 0, n_members = 0;
-    uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
-    uint32_t n_direct = 0, direct_first = 0;
-    mrt::SphereRec direct[mrt::kMaxDirect] = {};
-    float* d_vec4 = nullptr;
-    float* d_f32 = nullptr;
-    int32_t* d_i32 = nullptr;
-    uint32_t* d_seeds = nullptr;
-    float* d_fb[2] = {nullptr, nullptr};   // [target, secondary] ping-pong (lib.rs:505-543)
-    int target = 0;                        // index of the buffer the NEXT redraw writes
-    unsigned long long* d_counters = nullptr;
-    // Up to kFrameSlots frames may be in flight: frame n's render kernel (sort, pilot) runs on side
-    // stream n % kFrameSlots and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
-    // on the caller's stream.  The next frame's heavy tiles thus start while this frame's last
-    // pixels drain (a pixel is one sequential chain, so every frame ends on a thinning chip).
-    static constexpr uint32_t kFrameSlots = 2;      // 3 measured slower: a third persistent grid cannot become resident
-    struct FrameSlot {
-        hipStream_t stream = nullptr;
-        hipEvent_t render_done = nullptr, finalize_done = nullptr;
-        void* d_pix_acc = nullptr;             // per-pixel colour sums + costs, render -> finalize
-        uint32_t* d_tile_cost = nullptr;       // written by this slot's finalize, orders its next queue
-        uint32_t* d_tile_order = nullptr;
-        uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter
-        bool cost_valid = false;               // d_tile_cost holds a usable estimate for the current scene
-    } slot[kFrameSlots];
-    hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
-    bool inputs_dirty = true;
-    uint64_t frame_seq = 0;
-    uint32_t tiles_x = 0, n_tiles = 0, n_waves = 0, cus = 0;
-    uint32_t pilot_spp = 2;
-    int waves_per_cu_override = 0;
-    bool lpt_enabled = true;
-    unsigned long long* d_wave_log = nullptr;   // diagnostic, see mrt_debug_wave_log
-    size_t wave_log_waves = 0;
-
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    // ring of HIP event pairs around the render kernel of the most recent redraws
-    static constexpr uint32_t kEventRing = 64;
-    hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
-    uint64_t timed_frames = 0;             // redraws recorded so far
-
-    std::string err;
-};
-
 namespace {
 
 thread_local std::string g_err;   // for failures before a ctx exists
 
+}  // namespace
+
+namespace mrt {
 int fail(mrt_ctx* ctx, int status, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -115,17 +49,13 @@ int fail(mrt_ctx* ctx, int status, const char* fmt, ...) {
     if (ctx) ctx->err = buf; else g_err = buf;
     return status;
 }
+}  // namespace mrt
 
-#define HIP_TRY(ctx, expr)                                                                     \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(ctx, MRT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
-    } while (0)
+namespace {
 
-uint32_t total_bands(uint32_t height) { return (height + mrt::kBandRows - 1) / mrt::kBandRows; }
-
-size_t local_texels(const mrt_ctx* c) { return (size_t)c->local_bands * mrt::kBandRows * c->args.width; }
+using mrt::fail;
+using mrt::local_texels;
+using mrt::total_bands;
 
 void free_frame_buffers(mrt_ctx* c) {
     if (c->d_seeds) (void)hipFree(c->d_seeds);
@@ -768,6 +698,9 @@ void mrt_destroy(mrt_ctx* c) {
     free_world(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_wave_log) (void)hipFree(c->d_wave_log);
+    if (c->d_gather) (void)hipFree(c->d_gather);
+    if (c->d_gather_stage) (void)hipFree(c->d_gather_stage);
+    if (c->ev_gather) (void)hipEventDestroy(c->ev_gather);
     for (uint32_t i = 0; i < mrt_ctx::kEventRing; i++) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -795,9 +728,19 @@ int mrt_set_stream(mrt_ctx* c, void* s) {
     return MRT_OK;
 }
 
-int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t n_vec4,
+int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const float* vec4, size_t n_vec4,
                       const float* f32, size_t n_f32, const int32_t* i32, size_t n_i32) {
-    if (!c || !w) return MRT_ERR_INVALID_ARG;
+    if (!c || !world) return MRT_ERR_INVALID_ARG;
+    const auto t_begin = std::chrono::steady_clock::now();
+    // 64 bytes = the reference's raw::World (lib.rs:676-684) as it is; 80 = with the DielectricRange extension.
+    // Only world_bytes bytes of the caller's struct are read; a 64-byte World has no dielectrics.
+    if (world_bytes != MRT_WORLD_BYTES_REFERENCE && world_bytes != sizeof(mrt_world))
+        return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_world_raw: world_bytes %zu is neither %d (raw::World) nor %zu (mrt_world)",
+                    world_bytes, MRT_WORLD_BYTES_REFERENCE, sizeof(mrt_world));
+    mrt_world w_copy;
+    std::memset(&w_copy, 0, sizeof w_copy);
+    std::memcpy(&w_copy, world, world_bytes);
+    const mrt_world* const w = &w_copy;
     if ((n_vec4 && !vec4) || (n_f32 && !f32) || (n_i32 && !i32)) return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_world_raw: null array");
     const int64_t n = w->spheres.length;
     if (n < 0 || n > (int64_t)mrt::kMaxSpheres) return fail(c, MRT_ERR_BAD_SCENE, "spheres.length %lld out of range [0, %u]", (long long)n, mrt::kMaxSpheres);
@@ -895,6 +838,14 @@ int mrt_set_world_raw(mrt_ctx* c, const mrt_world* w, const float* vec4, size_t 
     c->n_direct = hier.n_direct; c->direct_first = hier.direct_first;
     for (uint32_t k = 0; k < mrt::kMaxDirect; k++) c->direct[k] = hier.direct[k];
     c->have_world = true;
+    c->set_world_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return MRT_OK;
+}
+
+int mrt_debug_last_set_world_ms(mrt_ctx* c, float* ms) {
+    if (!c || !ms) return MRT_ERR_INVALID_ARG;
+    if (!c->have_world) return fail(c, MRT_ERR_NO_SCENE, "mrt_debug_last_set_world_ms: no scene");
+    *ms = c->set_world_ms;
     return MRT_OK;
 }
 
@@ -906,7 +857,7 @@ int mrt_set_world(mrt_ctx* c, const mrt_sphere* spheres, size_t n) {
     size_t nv = 0, nf = 0, ni = 0;
     int st = mrt_pack_world(spheres, n, &w, vec4.data(), 2 * n + 1, &nv, f32.data(), 2 * n + 1, &nf, i32.data(), 2 * n + 1, &ni);
     if (st != MRT_OK) return fail(c, st, "mrt_set_world: packing failed (%s)", mrt_status_string(st));
-    return mrt_set_world_raw(c, &w, vec4.data(), nv, f32.data(), nf, i32.data(), ni);
+    return mrt_set_world_raw(c, &w, sizeof w, vec4.data(), nv, f32.data(), nf, i32.data(), ni);
 }
 
 int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
@@ -1164,6 +1115,7 @@ int mrt_reset(mrt_ctx* c) {
     HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    c->inputs_dirty = true;      // the next redraw's side stream waits for these memsets (ev_inputs)
     const uint32_t spp = c->locals.samples_per_frame, mode = c->locals.rng_mode;
     reset_locals(c);
     c->locals.samples_per_frame = spp;

@@ -1,7 +1,11 @@
 // Image writers (host only).  The reference never leaves the GPU: it presents the
 // accumulated RGBA32F texture to a window surface (raytracer/src/lib.rs:270-297,
 // sample_framebuffer.wgsl:38-41, with a Y flip at :24).  These writers are the headless
-// stand-in for that present pass.
+// stand-in for that present pass.  The surface the reference draws to is the adapter's default
+// format (surface.get_default_config, lib.rs:349-351; the fragment target takes that format,
+// lib.rs:1133), an sRGB format on every wgpu backend: the hardware applies the sRGB OETF to the
+// linear value fs_main returns (sample_framebuffer.wgsl:38-41) and rounds to 8 bits.  mrt_write_ppm
+// does the same conversion on the host.
 
 #include <cmath>
 #include <cstdio>
@@ -9,7 +13,19 @@
 
 #include "mrt_internal.h"
 
+// linear [0,1] -> 8-bit sRGB as a UNORM sRGB render target stores it: clamp, the piecewise OETF of
+// IEC 61966-2-1, round to nearest
+static unsigned char srgb8(float v) {
+    if (!(v > 0.0f)) return 0;                       // negatives and NaN clamp to 0
+    if (v >= 1.0f) return 255;
+    const double l = v;
+    const double e = l <= 0.0031308 ? 12.92 * l : 1.055 * std::pow(l, 1.0 / 2.4) - 0.055;
+    return (unsigned char)(e * 255.0 + 0.5);
+}
+
 extern "C" {
+
+uint8_t mrt_srgb8(float linear) { return srgb8(linear); }
 
 int mrt_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height) {
     if (!path || !rgba || !width || !height) return MRT_ERR_INVALID_ARG;
@@ -34,12 +50,7 @@ int mrt_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t 
     for (uint32_t y = 0; y < height; y++) {
         const float* src = rgba + (size_t)(height - 1 - y) * width * 4;   // flip: fb row 0 is the bottom
         for (uint32_t x = 0; x < width; x++) {
-            for (int ch = 0; ch < 3; ch++) {
-                float v = src[4 * x + ch];
-                v = (v > 0.0f) ? std::sqrt(v) : 0.0f;                      // gamma 2
-                if (!(v < 0.999f)) v = 0.999f;
-                row[3 * x + ch] = (unsigned char)(256.0f * v);
-            }
+            for (int ch = 0; ch < 3; ch++) row[3 * x + ch] = srgb8(src[4 * x + ch]);
         }
         if (std::fwrite(row.data(), 1, row.size(), f) != row.size()) { std::fclose(f); return MRT_ERR_IO; }
     }

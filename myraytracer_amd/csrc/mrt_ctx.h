@@ -1,0 +1,108 @@
+// Host-side state behind the opaque mrt_ctx of include/myraytracer_amd.h, shared by api.cpp (the frame loop)
+// and multi_gpu.cpp (the gather).  Internal: not installed.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+
+#include "mrt_internal.h"
+
+struct mrt_ctx {
+    int device = 0;
+    mrt_args args{};
+    uint64_t seed = 0;
+    mrt_locals locals{};
+    uint32_t frames_done = 0;          // State::sample_count (lib.rs:213, 300)
+
+    uint32_t shard_rank = 0, shard_world = 1;
+    uint32_t local_bands = 0;
+
+    mrt_world world{};
+    bool have_world = false;
+    uint32_t n_spheres = 0, n_padded = 0;
+    mrt_camera_raw cam_raw{};
+
+    // device memory (all owned)
+    mrt::SphereRec* d_spheres = nullptr;
+    mrt::SphereRec* d_clusters = nullptr;  // bounding spheres the sweep tests (up to kClusterK spheres each)
+    uint16_t* d_top_mfma = nullptr;        // the top-level records as the MFMA A operand (build_top_mfma)
+    bool mfma_scene_ok = false;            // the expanded test's extra slack is negligible for this scene
+    double mfma_r2_ref = 0.0;              // median R^2 of the top level (camera check at launch)
+    float mfma_origin[3] = {0.0f, 0.0f, 0.0f};   // the matrix-core sweep works in coordinates relative to this point
+    int sweep_mode = 0;                    // 0 automatic, 1 SGPR-fed VALU sweep, 2 matrix-core sweep (mrt_debug_set_sweep)
+    float* d_shade = nullptr;              // 8 floats per sphere: centre, radius, material colour, fuzz | ior
+    mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
+    uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
+    float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
+    uint32_t max_levels = mrt::kMaxLevels, top_target = 256;  // hierarchy depth rule (build_hierarchy)
+    uint32_t levels = 1, n_nodes = 0, n_members = 0;
+    uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
+    uint32_t n_direct = 0, direct_first = 0;
+    mrt::SphereRec direct[mrt::kMaxDirect] = {};
+    float* d_vec4 = nullptr;
+    float* d_f32 = nullptr;
+    int32_t* d_i32 = nullptr;
+    uint32_t* d_seeds = nullptr;
+    float* d_fb[2] = {nullptr, nullptr};   // [target, secondary] ping-pong (lib.rs:505-543)
+    int target = 0;                        // index of the buffer the NEXT redraw writes
+    unsigned long long* d_counters = nullptr;
+    // Up to kFrameSlots frames may be in flight: frame n's render kernel (sort, pilot) runs on side
+    // stream n % kFrameSlots and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
+    // on the caller's stream.  The next frame's heavy tiles thus start while this frame's last
+    // pixels drain (a pixel is one sequential chain, so every frame ends on a thinning chip).
+    static constexpr uint32_t kFrameSlots = 2;      // 3 measured slower: a third persistent grid cannot become resident
+    struct FrameSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t render_done = nullptr, finalize_done = nullptr;
+        void* d_pix_acc = nullptr;             // per-pixel colour sums + costs, render -> finalize
+        uint32_t* d_tile_cost = nullptr;       // written by this slot's finalize, orders its next queue
+        uint32_t* d_tile_order = nullptr;
+        uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter
+        bool cost_valid = false;               // d_tile_cost holds a usable estimate for the current scene
+    } slot[kFrameSlots];
+    hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
+    bool inputs_dirty = true;
+    uint64_t frame_seq = 0;
+    uint32_t tiles_x = 0, n_tiles = 0, n_waves = 0, cus = 0;
+    uint32_t pilot_spp = 2;
+    int waves_per_cu_override = 0;
+    bool lpt_enabled = true;
+    unsigned long long* d_wave_log = nullptr;   // diagnostic, see mrt_debug_wave_log
+    size_t wave_log_waves = 0;
+
+    // multi-GPU gather (multi_gpu.cpp): on the root, the full frame assembled from every shard's bands
+    // (total_bands_padded x 8 rows x W RGBA32F, row 0 = bottom) and, for the RCCL variant, the rank-major
+    // receive staging; ev_gather marks "this shard's bands have been copied out" on its stream
+    float* d_gather = nullptr;
+    float* d_gather_stage = nullptr;
+    size_t gather_bytes = 0, gather_stage_bytes = 0;
+    hipEvent_t ev_gather = nullptr;
+
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // ring of HIP event pairs around the render kernel of the most recent redraws
+    static constexpr uint32_t kEventRing = 64;
+    hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
+    uint64_t timed_frames = 0;             // redraws recorded so far
+
+    float set_world_ms = 0.0f;             // host time of the last scene upload (hierarchy build + copies)
+
+    std::string err;
+};
+
+namespace mrt {
+
+// records the message behind mrt_last_error (ctx == NULL: the thread's global message) and returns `status`
+int fail(mrt_ctx* ctx, int status, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+
+inline uint32_t total_bands(uint32_t height) { return (height + kBandRows - 1) / kBandRows; }
+inline size_t local_texels(const mrt_ctx* c) { return (size_t)c->local_bands * kBandRows * c->args.width; }
+
+}  // namespace mrt
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return mrt::fail(ctx, MRT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)

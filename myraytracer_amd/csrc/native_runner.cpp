@@ -3,6 +3,9 @@
 // driving the MI355X backend through the C ABI, plus what a windowless run needs
 // (--frames, --seed, --scene, --out, --device).  The reference renders forever into a
 // window (lib.rs:187-192); this renders --frames frames and writes the image.
+// --gpus N (devices 0..N-1) or --devices a,b,c tile-shards the frame over several GPUs from this one
+// process: one context per GPU, interleaved 8-row bands, one mrt_gather per frame onto the first device
+// (SURVEY.md 8e).  A device may be listed more than once (--devices 0,0 rehearses the path on one GPU).
 
 #include <chrono>
 #include <cstdio>
@@ -18,7 +21,7 @@ static void usage() {
         "usage: native_runner [--width N] [--height N] [--samples-per-frame N] [--ray-depth N]\n"
         "                     [--max-framebuffer-weight F] [--frames N] [--seed N]\n"
         "                     [--scene default|cover|cover-glass|stress | --scene-file FILE] [--save-scene FILE]\n"
-        "                     [--out FILE.pfm|FILE.ppm] [--device N]\n");
+        "                     [--out FILE.pfm|FILE.ppm] [--device N | --gpus N | --devices a,b,...]\n");
 }
 
 int main(int argc, char** argv) {
@@ -26,6 +29,7 @@ int main(int argc, char** argv) {
     mrt_args_default(&args);
     uint32_t frames = 1; uint64_t seed = 1; int device = 0;
     std::string scene = "default", scene_file, save_scene, out;
+    std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i], v;
         size_t eq = a.find('=');
@@ -45,6 +49,15 @@ int main(int argc, char** argv) {
         else if (a == "--save-scene") save_scene = v;
         else if (a == "--out") out = v;
         else if (a == "--device") device = std::atoi(v.c_str());
+        else if (a == "--gpus") { devices.clear(); for (int d = 0; d < std::atoi(v.c_str()); d++) devices.push_back(d); }
+        else if (a == "--devices") {
+            devices.clear();
+            for (size_t p0 = 0; p0 <= v.size();) {
+                const size_t p1 = v.find(',', p0) == std::string::npos ? v.size() : v.find(',', p0);
+                if (p1 > p0) devices.push_back(std::atoi(v.substr(p0, p1 - p0).c_str()));
+                p0 = p1 + 1;
+            }
+        }
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); usage(); return 2; }
     }
     mrt_args_resolve_size(&args);
@@ -70,29 +83,40 @@ int main(int argc, char** argv) {
         if (ss != MRT_OK) { std::fprintf(stderr, "%s: %s (%s)\n", save_scene.c_str(), mrt_status_string(ss), mrt_last_error(nullptr)); return 1; }
     }
 
-    mrt_ctx* ctx = nullptr;
-    int st = mrt_create(&args, seed, device, &ctx);
-    if (st != MRT_OK) { std::fprintf(stderr, "mrt_create: %s (%s)\n", mrt_status_string(st), mrt_last_error(nullptr)); return 1; }
-#define TRY(call) do { int s_ = (call); if (s_ != MRT_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, mrt_status_string(s_), mrt_last_error(ctx)); mrt_destroy(ctx); return 1; } } while (0)
-    TRY(mrt_set_world(ctx, spheres.data(), (size_t)n));
-    TRY(mrt_set_camera(ctx, &cam));
-    TRY(mrt_sync(ctx));
+    // one context per GPU; with a single device this is exactly the reference's one State
+    if (devices.empty()) devices.push_back(device);
+    const uint32_t n_gpus = (uint32_t)devices.size();
+    std::vector<mrt_ctx*> ctxs(n_gpus, nullptr);
+    auto destroy_all = [&]() { for (mrt_ctx* c : ctxs) mrt_destroy(c); };
+#define TRY(ctx, call) do { int s_ = (call); if (s_ != MRT_OK) { std::fprintf(stderr, "%s: %s (%s)\n", #call, mrt_status_string(s_), mrt_last_error(ctx)); destroy_all(); return 1; } } while (0)
+    for (uint32_t i = 0; i < n_gpus; i++) {
+        int st = mrt_create(&args, seed, devices[i], &ctxs[i]);
+        if (st != MRT_OK) { std::fprintf(stderr, "mrt_create(device %d): %s (%s)\n", devices[i], mrt_status_string(st), mrt_last_error(nullptr)); destroy_all(); return 1; }
+        if (n_gpus > 1) TRY(ctxs[i], mrt_set_shard(ctxs[i], i, n_gpus));
+        TRY(ctxs[i], mrt_set_world(ctxs[i], spheres.data(), (size_t)n));
+        TRY(ctxs[i], mrt_set_camera(ctxs[i], &cam));
+    }
+    for (mrt_ctx* c : ctxs) TRY(c, mrt_sync(c));
     auto t0 = std::chrono::steady_clock::now();
-    TRY(mrt_render(ctx, frames));
-    TRY(mrt_sync(ctx));
+    for (uint32_t f = 0; f < frames; f++) {
+        for (mrt_ctx* c : ctxs) TRY(c, mrt_redraw(c));                       // asynchronous: all GPUs render at once
+        if (n_gpus > 1) TRY(ctxs[0], mrt_gather(ctxs.data(), n_gpus, 0));     // every shard's bands -> the first GPU
+    }
+    for (mrt_ctx* c : ctxs) TRY(c, mrt_sync(c));
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double samples = (double)args.width * args.height * args.samples_per_frame * frames;
-    std::printf("%ux%u, %u spp x %u frames, depth %u, %d spheres: %.3f s, %.1f Msamples/s\n", args.width, args.height,
-                args.samples_per_frame, frames, args.ray_depth, n, sec, samples / sec * 1e-6);
+    std::printf("%ux%u, %u spp x %u frames, depth %u, %d spheres, %u GPU(s): %.3f s, %.1f Msamples/s\n", args.width, args.height,
+                args.samples_per_frame, frames, args.ray_depth, n, n_gpus, sec, samples / sec * 1e-6);
     if (!out.empty()) {
         std::vector<float> fb((size_t)args.width * args.height * 4);
-        TRY(mrt_read_framebuffer(ctx, fb.data(), fb.size()));
+        if (n_gpus > 1) TRY(ctxs[0], mrt_read_gathered(ctxs[0], fb.data(), fb.size()));
+        else TRY(ctxs[0], mrt_read_framebuffer(ctxs[0], fb.data(), fb.size()));
         const bool ppm = out.size() > 4 && out.substr(out.size() - 4) == ".ppm";
         int s2 = ppm ? mrt_write_ppm(out.c_str(), fb.data(), args.width, args.height)
                      : mrt_write_pfm(out.c_str(), fb.data(), args.width, args.height);
-        if (s2 != MRT_OK) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); mrt_destroy(ctx); return 1; }
+        if (s2 != MRT_OK) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); destroy_all(); return 1; }
         std::printf("wrote %s\n", out.c_str());
     }
-    mrt_destroy(ctx);
+    destroy_all();
     return 0;
 }

@@ -116,6 +116,10 @@ def lib():
         L.orc_render_rows.argtypes = [C.POINTER(Locals), C.POINTER(World), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.POINTER(CameraRaw), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Counters)]
+        L.orc_render_rect.argtypes = [C.POINTER(Locals), C.POINTER(World), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.POINTER(CameraRaw), C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.POINTER(Counters)]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -185,8 +189,9 @@ def lookat_camera(lookfrom, lookat, vup, vfov, defocus_angle, focus_dist):
 
 
 def render_frame(width, height, spp, depth, packed, cam, seeds, shuffle=(0, 0, 0, 0), weight=0.0,
-                 prev=None, rows=None, nthreads=0, counters=None, rng_mode=0):
-    """One pass of fs_main (shader.wgsl:371-386) over rows [rows[0], rows[1]) -> (H,W,4) f32, row 0 = bottom."""
+                 prev=None, rows=None, nthreads=0, counters=None, rng_mode=0, cols=None):
+    """One pass of fs_main (shader.wgsl:371-386) over rows [rows[0], rows[1]) (and columns [cols[0], cols[1]))
+    -> (H,W,4) f32, row 0 = bottom; texels outside the rectangle stay 0."""
     L = Locals()
     L.shape[0], L.shape[1] = width, height
     L.samples_per_frame, L.ray_depth = spp, depth
@@ -201,9 +206,10 @@ def render_frame(width, height, spp, depth, packed, cam, seeds, shuffle=(0, 0, 0
     out = np.zeros((height, width, 4), np.float32)
     y0, y1 = (0, height) if rows is None else rows
     raw = camera_derive(cam) if isinstance(cam, Camera) else cam
-    lib().orc_render_rows(C.byref(L), C.byref(packed.world), _ptr(packed.vec4), _ptr(packed.f32),
+    x0, x1 = (0, width) if cols is None else cols
+    lib().orc_render_rect(C.byref(L), C.byref(packed.world), _ptr(packed.vec4), _ptr(packed.f32),
                           _ptr(packed.i32), C.byref(raw), _ptr(seeds), _ptr(prev), _ptr(out),
-                          y0, y1, nthreads, C.byref(counters) if counters is not None else None)
+                          x0, x1, y0, y1, nthreads, C.byref(counters) if counters is not None else None)
     return out
 
 

@@ -410,32 +410,42 @@ int orc_max_threads(void) {
 #endif
 }
 
-void orc_render_rows(const orc_locals* locals, const orc_world* world,
+void orc_render_rect(const orc_locals* locals, const orc_world* world,
                      const float* vec4, const float* f32, const int32_t* i32,
                      const orc_camera_raw* cam, const uint32_t* seeds,
                      const float* prev, float* out,
-                     uint32_t y0, uint32_t y1, int nthreads, orc_counters* counters) {
+                     uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int nthreads, orc_counters* counters) {
     scene_t s = {world, vec4, f32, i32};
     orc_counters total; memset(&total, 0, sizeof total);
-    const uint32_t W = locals->shape[0];
+    if (x1 <= x0 || y1 <= y0) return;
+    const int64_t rw = (int64_t)(x1 - x0), n = rw * (int64_t)(y1 - y0);
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
 #pragma omp parallel num_threads(nthreads)
 #endif
     {
         orc_counters local; memset(&local, 0, sizeof local);
+        /* pixels are independent (own stream, own texel), so any order gives the same image and the same
+         * (integer) counter totals */
 #ifdef _OPENMP
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for schedule(dynamic, 16)
 #endif
-        for (int64_t y = (int64_t)y0; y < (int64_t)y1; y++)
-            for (uint32_t x = 0; x < W; x++)
-                shade_pixel(locals, &s, cam, seeds, prev, out, x, (uint32_t)y, &local);
+        for (int64_t k = 0; k < n; k++)
+            shade_pixel(locals, &s, cam, seeds, prev, out, x0 + (uint32_t)(k % rw), y0 + (uint32_t)(k / rw), &local);
 #ifdef _OPENMP
 #pragma omp critical
 #endif
         counters_add(&total, &local);
     }
     if (counters) counters_add(counters, &total);
+}
+
+void orc_render_rows(const orc_locals* locals, const orc_world* world,
+                     const float* vec4, const float* f32, const int32_t* i32,
+                     const orc_camera_raw* cam, const uint32_t* seeds,
+                     const float* prev, float* out,
+                     uint32_t y0, uint32_t y1, int nthreads, orc_counters* counters) {
+    orc_render_rect(locals, world, vec4, f32, i32, cam, seeds, prev, out, 0u, locals->shape[0], y0, y1, nthreads, counters);
 }
 
 /* ------------------------------------------------------------------ exported unit hooks */

@@ -130,6 +130,14 @@ void orc_render_rows(const orc_locals* locals, const orc_world* world,
                      const float* prev, float* out,
                      uint32_t y0, uint32_t y1, int nthreads, orc_counters* counters);
 
+/* the same over the pixel rectangle [x0,x1) x [y0,y1) only (other texels of `out` are left untouched);
+ * threads share the rectangle's pixels, so a single row also uses every core */
+void orc_render_rect(const orc_locals* locals, const orc_world* world,
+                     const float* vec4, const float* f32, const int32_t* i32,
+                     const orc_camera_raw* cam, const uint32_t* seeds,
+                     const float* prev, float* out,
+                     uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int nthreads, orc_counters* counters);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported(mrt):
 def test_abi_version_and_status_strings(mrt):
     from myraytracer_amd import _lib
     L = _lib.load()
-    assert L.mrt_abi_version() == 1
+    assert L.mrt_abi_version() == 2
     assert L.mrt_status_string(0) == b"ok"
     assert L.mrt_status_string(2) == b"no usable HIP device"
     assert L.mrt_last_error(None) is not None
@@ -72,3 +72,29 @@ def test_hand_issued_scalar_loads_are_safe_in_the_built_isa():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_isa.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def build_c_caller(tmp_path):
+    """gcc tests/abi_c_caller.c against the in-tree .so, as a C (or Rust FFI) consumer of the header would."""
+    import subprocess
+    exe = str(tmp_path / "abi_c_caller")
+    libdir = os.path.join(ROOT, "myraytracer_amd", "lib")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "abi_c_caller.c"),
+                           "-L" + libdir, "-lmyraytracer_amd", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_plain_c_caller_links_and_packs_like_the_reference(mrt, tmp_path):
+    """The header compiles as C, the .so links from C, and the reference's 64-byte raw::World of the shipped scene
+    (built by hand in C from lib.rs:687-799) is bit-identical to the first 64 bytes mrt_pack_world produces."""
+    import subprocess
+    r = subprocess.run([build_c_caller(tmp_path), "host"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "host ok" in r.stdout
+
+
+def test_pytest_collects_only_tests_dir():
+    """pytest.ini pins testpaths: scripts/ (GPU experiments) must never be collected."""
+    ini = open(os.path.join(ROOT, "pytest.ini")).read()
+    assert "testpaths = tests" in ini
+    assert not [f for f in os.listdir(os.path.join(ROOT, "scripts")) if f.endswith("_test.py") or f.startswith("test_")]

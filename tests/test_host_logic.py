@@ -108,7 +108,51 @@ def test_image_writers(mrt, tmp_path):
     raw = open(p, "rb").read()
     assert raw.startswith(b"P6\n4 3\n255\n")
     body = np.frombuffer(raw[len(b"P6\n4 3\n255\n"):], np.uint8).reshape(3, 4, 3)
-    assert body[2, 0, 0] == 255 and body[0, 0, 2] == 128 and body[1].sum() == 0     # flipped, gamma 2
+    assert body[2, 0, 0] == 255 and body[0, 0, 2] == 137 and body[1].sum() == 0     # flipped, sRGB OETF
+
+
+def test_ppm_is_the_srgb_surface_encoding(mrt):
+    """lib.rs:349-351 / :1133: the present pass stores linear values to the adapter's sRGB surface, i.e. the
+    piecewise sRGB OETF rounded to 8 bits -- not a gamma-2 square root."""
+    L = mrt._lib.load()
+    known = {0.0: 0, 1.0: 255, 2.0: 255, -1.0: 0, 0.5: 188, 0.25: 137, 0.2140: 127, 0.0031308: 10, 0.001: 3, 0.01: 25, 0.18: 118}
+    for lin, code in known.items():
+        assert L.mrt_srgb8(lin) == code, (lin, L.mrt_srgb8(lin), code)
+    assert L.mrt_srgb8(float("nan")) == 0
+    # against the closed form on a sweep, and monotonic
+    xs = np.linspace(0.0, 1.0, 4001, dtype=np.float32)
+    got = np.array([L.mrt_srgb8(float(x)) for x in xs])
+    x64 = xs.astype(np.float64)
+    enc = np.where(x64 <= 0.0031308, 12.92 * x64, 1.055 * np.power(x64, 1 / 2.4) - 0.055)
+    assert np.array_equal(got, np.floor(enc * 255.0 + 0.5).astype(int))
+    assert (np.diff(got) >= 0).all()
+
+
+def test_unshard_rows_in_cxx_matches_the_band_layout(mrt):
+    """The band un-permute of the multi-GPU gather, host side in C++ (mrt_unshard_rows / mrt_shard_global_row),
+    without torch or gloo: shard (r, N) holds the 8-row bands b with b % N == r, packed."""
+    rng = np.random.default_rng(3)
+    for height, width, world in ((27, 5, 2), (64, 3, 8), (1080, 2, 8), (9, 4, 3), (8, 1, 1), (100, 2, 7)):
+        full = rng.random((height, width, 4), dtype=np.float32)
+        lrows = mrt.shard_local_rows(height, world)
+        nb = (height + 7) // 8
+        assert lrows == ((nb + world - 1) // world) * 8
+        packed = np.zeros((world, lrows, width, 4), np.float32)
+        seen = np.zeros(height, int)
+        for r in range(world):
+            for lr in range(lrows):
+                g = mrt.shard_global_row(lr, r, world)
+                assert g == ((lr // 8) * world + r) * 8 + lr % 8
+                if g < height:
+                    packed[r, lr] = full[g]
+                    seen[g] += 1
+        assert (seen == 1).all()                      # every row belongs to exactly one shard
+        assert np.array_equal(mrt.unshard_rows(packed, height), full)
+    # agrees with the torch-side un-permute used by the one-process-per-GPU path
+    import torch
+    from myraytracer_amd import dist as mdist
+    packed = rng.random((3, mrt.shard_local_rows(50, 3), 4, 4), dtype=np.float32)
+    assert np.array_equal(mrt.unshard_rows(packed, 50), mdist.unshard(torch.from_numpy(packed), 50).numpy())
 
 
 def test_scene_files_round_trip_every_bit(mrt, tmp_path):
