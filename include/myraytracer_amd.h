@@ -276,6 +276,15 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
                               float* top_out, size_t top_cap, float* nodes_out, size_t nodes_cap,
                               uint32_t* member_index_out, size_t member_cap, uint16_t* mfma_out, size_t mfma_cap,
                               float mfma_origin_out[3], uint32_t info[10]);
+/* Diagnostic: ONE world_hit (shader.wgsl:314-329, range [0.001, 1e4)) for each of n caller-supplied rays -- rays[6 i ..] =
+ * origin xyz, direction xyz; directions of unit length to 1e-5, as every ray of the render loop is -- through the very sweep +
+ * walk the render kernel runs (the same kernel, instantiated to take its rays from this array), with the current scene,
+ * hierarchy and sweep variant.  hit_out[2 i] = index of the closest sphere or -1, hit_out[2 i + 1] = the bits of its t;
+ * candidates_out (optional): cand_words_per_ray >= ceil(spheres/32) words per ray, bit s set iff sphere s reached the root
+ * tests, i.e. passed the conservative sweep, every level of the walk AND the exact discriminant test.  The conservativeness
+ * claim of DESIGN.md 4 is that this set equals {s : discriminant_s >= 0} for every ray (tests/test_gpu_superset.py). */
+int mrt_debug_world_hit(mrt_ctx* ctx, const float* rays, size_t n, int32_t* hit_out, uint32_t* candidates_out,
+                        size_t cand_words_per_ray);
 /* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
 int mrt_debug_sweep_variant(mrt_ctx* ctx);
 /* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */

@@ -378,6 +378,19 @@ class State:
         self._check(self._L.mrt_debug_read_pixel_costs(self._ctx, packed.ctypes.data, packed.size), "mrt_debug_read_pixel_costs")
         return packed[:self.args.height] if world == 1 else packed
 
+    def debug_world_hit(self, rays: np.ndarray, n_spheres: int):
+        """One world_hit per ray (rays: (n, 6) f32 = origin, unit direction) through the render kernel's sweep + walk.
+        Returns (hit index (n,) i32 [-1 = miss], t (n,) f32, candidates (n, n_spheres) bool = spheres that reached the root
+        tests)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n, words = len(rays), max(1, (n_spheres + 31) // 32)
+        hit = np.empty((n, 2), np.int32)
+        cand = np.zeros((n, words), np.uint32)
+        self._check(self._L.mrt_debug_world_hit(self._ctx, rays.ctypes.data, n, hit.ctypes.data, cand.ctypes.data, words),
+                    "mrt_debug_world_hit")
+        bits = np.unpackbits(cand.view(np.uint8), axis=1, bitorder="little")[:, :n_spheres].astype(bool)
+        return hit[:, 0].copy(), hit[:, 1].copy().view(np.float32), bits
+
     def last_set_world_ms(self) -> float:
         """Host wall time of the last scene upload (hierarchy build + copies); one-off per scene."""
         ms = C.c_float()

@@ -821,7 +821,15 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
             std::memcpy(sh + 4, vec4 + 4 * (w->metals.albedo_base_idx + mi), 3 * sizeof(float));
             sh[7] = f32[w->metals.fuzz_base_idx + mi];
         } else if (ty == MRT_DIELECTRIC) {
-            sh[7] = f32[w->dielectrics.ior_base_idx + mi];
+            // A Dielectric attenuates by (1,1,1) (a constant in the kernel), so its colour slots carry what its
+            // scatter derives from the sphere alone, evaluated here with the same f32 operations in the same order
+            // (correctly rounded '/', no contraction): ri = 1/ior for a front-face hit, and the Schlick r0 =
+            // ((1-ri)/(1+ri))^2 for either face.  Bit-identical to evaluating them per hit.
+            const float ior = f32[w->dielectrics.ior_base_idx + mi];
+            auto schlick_r0 = [](float ri) { float r0 = (1.0f - ri) / (1.0f + ri); return r0 * r0; };
+            const float inv_ior = 1.0f / ior;
+            sh[4] = inv_ior; sh[5] = schlick_r0(inv_ior); sh[6] = schlick_r0(ior);
+            sh[7] = ior;
         }
     }
     HIP_TRY(c, upload((void**)&c->d_shade, shade.data(), shade.size() * sizeof(float)));
@@ -917,15 +925,10 @@ int mrt_read_seeds(mrt_ctx* c, uint32_t* out, size_t cap) {
     return MRT_OK;
 }
 
-// State::redraw, lib.rs:241-307 (raytrace pass + swap + weight/shuffle update; the present
-// pass needs a window surface and is out of scope)
-int mrt_redraw(mrt_ctx* c) {
-    if (!c) return MRT_ERR_INVALID_ARG;
-    if (!c->have_world) return fail(c, MRT_ERR_NO_SCENE, "mrt_redraw: no scene (call mrt_set_world first)");
-    HIP_TRY(c, hipSetDevice(c->device));
-    mrt::KParams p;
-    std::memset(&p, 0, sizeof p);
-    p.locals = c->locals;
+}  // extern "C"
+
+// the scene / hierarchy / sweep-variant part of the kernel arguments (everything that does not depend on the frame)
+static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     p.world = c->world;
     p.cam = c->cam_raw;
     p.n_spheres = c->n_spheres;
@@ -940,9 +943,23 @@ int mrt_redraw(mrt_ctx* c) {
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) p.level_base[k] = c->level_base[k];
     p.n_direct = c->n_direct; p.direct_first = c->direct_first;
     for (uint32_t k = 0; k < mrt::kMaxDirect; k++) p.direct[k] = c->direct[k];
-    p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.cus = c->cus;
     p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.top_mfma = c->d_top_mfma; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.shade = c->d_shade; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
+}
+
+extern "C" {
+
+// State::redraw, lib.rs:241-307 (raytrace pass + swap + weight/shuffle update; the present
+// pass needs a window surface and is out of scope)
+int mrt_redraw(mrt_ctx* c) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    if (!c->have_world) return fail(c, MRT_ERR_NO_SCENE, "mrt_redraw: no scene (call mrt_set_world first)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    mrt::KParams p;
+    std::memset(&p, 0, sizeof p);
+    p.locals = c->locals;
+    fill_scene_params(c, p);
+    p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.seeds = c->d_seeds;
     p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
     p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
@@ -1065,6 +1082,60 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
     if (member_index_out) std::memcpy(member_index_out, h.member_index.data(), h.member_index.size() * sizeof(uint32_t));
     if (mfma_out) std::memcpy(mfma_out, mf.data(), mf.size() * sizeof(uint16_t));
     if (mfma_origin_out) for (int k = 0; k < 3; k++) mfma_origin_out[k] = origin[k];
+    return MRT_OK;
+}
+
+int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_out, uint32_t* cand_out, size_t cand_words) {
+    if (!c || !rays || !hit_out || n == 0) return MRT_ERR_INVALID_ARG;
+    if (!c->have_world) return fail(c, MRT_ERR_NO_SCENE, "mrt_debug_world_hit: no scene");
+    const size_t need_words = ((size_t)c->n_spheres + 31) / 32;
+    if (cand_out && cand_words < need_words) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_world_hit: need %zu bitmap words per ray", need_words);
+    if (n > (1u << 26)) return fail(c, MRT_ERR_INVALID_ARG, "mrt_debug_world_hit: too many rays");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, sync_all(c));
+    // rays become the texels of an 8-pixel-wide virtual image (one 8x8 tile per 64 rays), padded with copies of ray 0
+    const size_t n_pad = (n + 63) / 64 * 64;
+    const size_t words = need_words ? need_words : 1;
+    std::vector<float> host_rays(6 * n_pad);
+    std::memcpy(host_rays.data(), rays, 6 * n * sizeof(float));
+    for (size_t i = n; i < n_pad; i++) std::memcpy(host_rays.data() + 6 * i, rays, 6 * sizeof(float));
+    float* d_rays = nullptr; int32_t* d_hit = nullptr; uint32_t* d_cand = nullptr; uint32_t* d_queue = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_rays); (void)hipFree(d_hit); (void)hipFree(d_cand); (void)hipFree(d_queue); };
+    hipError_t e = hipMalloc((void**)&d_rays, host_rays.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_hit, n_pad * 2 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_cand, n_pad * words * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_queue, 64);
+    if (e == hipSuccess) e = hipMemcpy(d_rays, host_rays.data(), host_rays.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_cand, 0, n_pad * words * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(d_hit, 0xFF, n_pad * 2 * sizeof(int32_t));
+    if (e != hipSuccess) { cleanup(); return fail(c, MRT_ERR_HIP, "mrt_debug_world_hit: %s", hipGetErrorString(e)); }
+    mrt::KParams p;
+    std::memset(&p, 0, sizeof p);
+    p.locals = c->locals;
+    p.locals.shape[0] = 8; p.locals.shape[1] = (uint32_t)(n_pad / 8);
+    p.locals.samples_per_frame = 1; p.locals.ray_depth = 1;
+    fill_scene_params(c, p);
+    p.shard_rank = 0; p.shard_world = 1;
+    p.tiles_x = 1; p.n_tiles = (uint32_t)(n_pad / 64);
+    p.tile_queue = d_queue;
+    p.dbg_rays = d_rays; p.dbg_hit = d_hit; p.dbg_cand = d_cand; p.dbg_words = (uint32_t)words;
+    int le = mrt::launch_debug_world_hit(p, c->n_waves, c->stream);
+    if (le == 0) e = hipStreamSynchronize(c->stream);
+    if (le != 0 || e != hipSuccess) { cleanup(); return fail(c, MRT_ERR_HIP, "mrt_debug_world_hit: launch failed: %s", hipGetErrorString(le ? (hipError_t)le : e)); }
+    std::vector<int32_t> hits(n_pad * 2);
+    e = hipMemcpy(hits.data(), d_hit, hits.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) std::memcpy(hit_out, hits.data(), n * 2 * sizeof(int32_t));
+    if (e == hipSuccess && cand_out) {
+        std::vector<uint32_t> cand(n_pad * words);
+        e = hipMemcpy(cand.data(), d_cand, cand.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            for (size_t i = 0; i < n; i++) {
+                std::memset(cand_out + i * cand_words, 0, cand_words * sizeof(uint32_t));
+                std::memcpy(cand_out + i * cand_words, cand.data() + i * words, need_words * sizeof(uint32_t));
+            }
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(c, MRT_ERR_HIP, "mrt_debug_world_hit: read-back failed: %s", hipGetErrorString(e));
     return MRT_OK;
 }
 

@@ -345,7 +345,10 @@ __device__ __forceinline__ KArgPtr cold_args() {
 // the walk gathers per item -- an L1 round trip per candidate cluster otherwise.  SMALL also means
 // that every node id fits 10 bits, so the work items are u16.
 constexpr uint32_t kWavesPerGroup = 4;
-template <bool COUNT, bool PILOT, bool CTR, bool SMALL, bool MFMA>
+// DBG (mrt_debug_world_hit): the same sweep + walk for caller-supplied rays instead of camera rays -- a lane's "pixel"
+// is ray number `texel` of P.dbg_rays, traced once; the winner goes to P.dbg_hit and every (ray, sphere) that
+// reaches the root tests is recorded in P.dbg_cand.  Nothing else of the kernel changes.
+template <bool COUNT, bool PILOT, bool CTR, bool SMALL, bool MFMA, bool DBG = false>
 __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(5, 8))) render_kernel(const KParams P) {
     typedef typename Ent<SMALL>::type entry_t;
     constexpr uint32_t kIdBits = Ent<SMALL>::id_bits;
@@ -416,8 +419,10 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         // ---- release: the pixel's last sample is done -> leave its colour sum for finalize_kernel
         const bool release = has_task && task_done;
         if (release) {
-            PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
-            reinterpret_cast<PixAcc*>(cold_args()->pix_acc)[texel] = sa;
+            if (!DBG) {
+                PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
+                reinterpret_cast<PixAcc*>(cold_args()->pix_acc)[texel] = sa;
+            }
             has_task = false;
         }
         // ---- refill: lanes would run dry -> take the next (heaviest remaining) tile of the frame
@@ -464,6 +469,14 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 has_task = true;
                 task_done = (spp == 0u);                // nothing to draw: colour 0/0, as the reference
                 need_sample = !task_done;
+                if (DBG) {
+                    const float* const r6 = C->dbg_rays + 6u * (size_t)texel;
+                    o = v3(r6[0], r6[1], r6[2]);
+                    d = v3(r6[3], r6[4], r6[5]);
+                    depth_left = 1u;
+                    task_done = false;
+                    need_sample = false;
+                }
             }
             const uint32_t np = (uint32_t)__popcll(need);
             const uint32_t took = np < avail ? np : avail;
@@ -478,57 +491,58 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         MRT_STAMP(5);
 
         const bool live = has_task && !task_done;
-        if (COUNT) started += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && need_sample));
-        if (live) {
-            pix_trips++;
-            if (need_sample) {
-                if (CTR) {      // extension: this sample's state = hash(pixel frame state, sample index)
-                    const uint32_t k4 = 4u * s_done;
-                    rng.s0 = fmix32(base0 + 0x9E3779B9u * (k4 + 1u));
-                    rng.s1 = fmix32(base1 + 0x9E3779B9u * (k4 + 2u));
-                    rng.s2 = fmix32(base2 + 0x9E3779B9u * (k4 + 3u));
-                    rng.s3 = fmix32(base3 + 0x9E3779B9u * (k4 + 4u));
-                    if ((rng.s0 | rng.s1 | rng.s2 | rng.s3) == 0u) {
-                        rng.s0 = 0x9E3779B9u; rng.s1 = 0x7F4A7C15u; rng.s2 = 0xBF58476Du; rng.s3 = 0x1CE4E5B9u;
-                    }
+        // One trip of the sample loop head, shader.wgsl:378-381: seeds the path (o, pre-normalised direction nd).
+        // It runs at the TAIL of the iteration in which a lane's path ended (or in which the lane acquired its
+        // pixel: such a lane sits out that iteration's world_hit, once per pixel), so that the new camera ray and
+        // the scattered rays share one normalize (:354 / :381) and every lane enters the next world_hit with a
+        // ray.  Per lane the draw order is the reference's: jitter, lens, then the path's draws.
+        auto new_sample = [&](V3& nd) {
+            if (CTR) {      // extension: this sample's state = hash(pixel frame state, sample index)
+                const uint32_t k4 = 4u * s_done;
+                rng.s0 = fmix32(base0 + 0x9E3779B9u * (k4 + 1u));
+                rng.s1 = fmix32(base1 + 0x9E3779B9u * (k4 + 2u));
+                rng.s2 = fmix32(base2 + 0x9E3779B9u * (k4 + 3u));
+                rng.s3 = fmix32(base3 + 0x9E3779B9u * (k4 + 4u));
+                if ((rng.s0 | rng.s1 | rng.s2 | rng.s3) == 0u) {
+                    rng.s0 = 0x9E3779B9u; rng.s1 = 0x7F4A7C15u; rng.s2 = 0xBF58476Du; rng.s3 = 0x1CE4E5B9u;
                 }
-                // one trip of the sample loop head, shader.wgsl:378-381
-                float u = rng_f32(rng); float v = rng_f32(rng);            // :71-75, x then y
-                float vx = base_x + u * pixel_side;
-                float vy = base_y + v * pixel_side;
-                const KArgPtr C = cold_args();
-                if (C->cam.mode == 0) {
-                    o = v3(0.0f, 0.0f, 0.0f);                               // ORIGIN, :361
-                    d = normalize3(v3(vx, vy, -1.0f));                      // :381
-                } else {
-                    // extension: look-at thin-lens camera over the same (vx, vy)
-                    V3 p = v3((vx * C->cam.su[0] + vy * C->cam.sv[0]) - C->cam.fw[0],
-                              (vx * C->cam.su[1] + vy * C->cam.sv[1]) - C->cam.fw[1],
-                              (vx * C->cam.su[2] + vy * C->cam.sv[2]) - C->cam.fw[2]);
-                    o = v3(C->cam.origin[0], C->cam.origin[1], C->cam.origin[2]);
-                    if (C->cam.defocus) {
-                        float lx, ly;
-                        do {                                                // unit disk by rejection
-                            lx = rng_pm1(rng); ly = rng_pm1(rng);
-                        } while (__builtin_fmaf(ly, ly, lx * lx) > 1.0f);
-                        V3 off = v3(lx * C->cam.ru[0] + ly * C->cam.rv[0],
-                                    lx * C->cam.ru[1] + ly * C->cam.rv[1],
-                                    lx * C->cam.ru[2] + ly * C->cam.rv[2]);
-                        o = o + off;
-                        d = normalize3(p - off);
-                    } else {
-                        d = normalize3(p);
-                    }
-                }
-                att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
-                depth_left = C->locals.ray_depth;
-                need_sample = false;
             }
-        }
+            float u = rng_f32(rng); float v = rng_f32(rng);            // :71-75, x then y
+            float vx = base_x + u * pixel_side;
+            float vy = base_y + v * pixel_side;
+            const KArgPtr C = cold_args();
+            if (C->cam.mode == 0) {
+                o = v3(0.0f, 0.0f, 0.0f);                               // ORIGIN, :361
+                nd = v3(vx, vy, -1.0f);                                 // :381 before normalize()
+            } else {
+                // extension: look-at thin-lens camera over the same (vx, vy)
+                V3 p = v3((vx * C->cam.su[0] + vy * C->cam.sv[0]) - C->cam.fw[0],
+                          (vx * C->cam.su[1] + vy * C->cam.sv[1]) - C->cam.fw[1],
+                          (vx * C->cam.su[2] + vy * C->cam.sv[2]) - C->cam.fw[2]);
+                o = v3(C->cam.origin[0], C->cam.origin[1], C->cam.origin[2]);
+                if (C->cam.defocus) {
+                    float lx, ly;
+                    do {                                                // unit disk by rejection
+                                    lx = rng_pm1(rng); ly = rng_pm1(rng);
+                    } while (__builtin_fmaf(ly, ly, lx * lx) > 1.0f);
+                    V3 off = v3(lx * C->cam.ru[0] + ly * C->cam.rv[0],
+                                lx * C->cam.ru[1] + ly * C->cam.rv[1],
+                                lx * C->cam.ru[2] + ly * C->cam.rv[2]);
+                    o = o + off;
+                    nd = p - off;
+                } else {
+                    nd = p;
+                }
+            }
+            att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
+            depth_left = C->locals.ray_depth;
+        };
+        const bool fresh = live && need_sample;         // pixel acquired in this iteration: nothing to trace or shade yet
+        if (live && !fresh) pix_trips++;
         MRT_STAMP(0);
 
         // ------------------------------------------------------------ world_hit, shader.wgsl:314-329
-        const bool trace = live && depth_left != 0u;                        // lanes inside the loop of :339
+        const bool trace = live && !fresh && depth_left != 0u;              // lanes inside the loop of :339
         if (COUNT) bounces += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(trace));
         float t_sup = 1.0e4f;                                               // :340
         int32_t best = -1;
@@ -767,6 +781,10 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         // for the index load to hide behind)
                         const unsigned long long key = (act && (ok_near || ok_far)) ? (((unsigned long long)__float_as_uint(t) << 32) | sidx) : kNoHitKey;
                         atomicMin(best_slots + 4u * owner, key);
+                        if (DBG) {      // this (ray, sphere) passed the sweep, the walk and the exact discriminant
+                            const uint32_t owner_ray = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)texel);
+                            if (act) atomicOr(P.dbg_cand + (size_t)owner_ray * P.dbg_words + (sidx >> 5), 1u << (sidx & 31u));
+                        }
                         qn[0] = start;
 #ifdef MRT_STAMPS
                         rounds_b_++; items_b_ += take;
@@ -788,11 +806,22 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             }
         }
         MRT_STAMP(3);
+        if (DBG) {
+            if (live) {
+                P.dbg_hit[2u * texel] = best;
+                P.dbg_hit[2u * texel + 1u] = (int32_t)__float_as_uint(t_sup);
+                task_done = true;
+            }
+            continue;
+        }
 
+        bool start_sample = false;
         if (live) {
             bool path_done = false;
-            V3 contrib = v3(0.0f, 0.0f, 0.0f);
-            if (depth_left == 0u) {
+            V3 contrib = v3(0.0f, 0.0f, 0.0f), ndir = d;
+            if (fresh) {
+                // handled below: the pixel's first sample
+            } else if (depth_left == 0u) {
                 path_done = true;                                           // loop :339 not entered -> :357
             } else {
                 if (best < 0) {
@@ -817,7 +846,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     if (!front_face) normal = -normal;
 
                     // dyn_material_scatter, shader.wgsl:244-252
-                    V3 albedo = v3(sh1.x, sh1.y, sh1.z), ndir = d;
+                    V3 albedo = v3(sh1.x, sh1.y, sh1.z);
                     bool scattered;
                     // Lambertian and Metal both start with one unit-ball sample (:209 via :92-94, :236): one
                     // rejection loop for the lanes of either kind (each lane still draws only its own numbers)
@@ -834,15 +863,17 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         ndir = v3(refl.x + fuzz * ball.x, refl.y + fuzz * ball.y, refl.z + fuzz * ball.z);
                         scattered = !(dot3(ndir, normal) <= 0.0f);
                     } else if (m_ty == MRT_DIELECTRIC) {                    // extension, DESIGN.md §3
+                        // The quantities that depend on the sphere alone come from its shading record, evaluated by
+                        // the host with the same f32 operations (api.cpp): 1/ior and ((1-ri)/(1+ri))^2 for ri = 1/ior
+                        // (front face) and ri = ior (back face).  The attenuation of a Dielectric is (1,1,1).
                         const float ior = sh1.w;
+                        const float ri = front_face ? sh1.x : ior;
+                        const float r0 = front_face ? sh1.y : sh1.z;
                         albedo = v3(1.0f, 1.0f, 1.0f);
-                        const float ri = front_face ? (1.0f / ior) : ior;
                         float cos_t = dot3(-d, normal);
                         cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;
                         const float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
                         const bool cannot_refract = (ri * sin_t) > 1.0f;
-                        float r0 = (1.0f - ri) / (1.0f + ri);
-                        r0 = r0 * r0;
                         const float x1 = 1.0f - cos_t;
                         const float x2 = x1 * x1; const float x4 = x2 * x2; const float x5 = x4 * x1;
                         const float reflectance = r0 + (1.0f - r0) * x5;
@@ -865,7 +896,6 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     } else {
                         att = att * albedo;                                 // :353
                         o = at;
-                        d = normalize3(ndir);                               // :354
                         depth_left--;
                         if (depth_left == 0u) path_done = true;             // loop ends -> :357 vec3(0)
                     }
@@ -873,12 +903,21 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             }
 
             MRT_STAMP(4);
+            start_sample = fresh;
             if (path_done) {
                 color = color + contrib;                                    // :381
                 s_done++;
-                if (s_done < spp) need_sample = true; else task_done = true;
+                if (s_done < spp) start_sample = true; else task_done = true;
             }
+            if (start_sample) {
+                new_sample(ndir);
+                need_sample = false;
+            }
+            // normalize() of the scattered direction (:354) and of the next sample's camera ray (:381), one code
+            // path for the lanes of either kind
+            if (!task_done) d = normalize3(ndir);
         }
+        if (COUNT) started += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(start_sample));
     }
 
     if (COUNT && !PILOT) {
@@ -1017,6 +1056,27 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
         MRT_LAUNCH(false, false, false);
     }
 #undef MRT_LAUNCH
+    return (int)hipGetLastError();
+}
+
+// mrt_debug_world_hit: one world_hit per ray of p.dbg_rays (an 8-wide virtual image, ray = texel index)
+int launch_debug_world_hit(const KParams& p, uint32_t n_waves, void* stream) {
+    if (p.n_tiles == 0 || n_waves == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return (int)e;
+    const bool small = scene_is_small(p);
+    const uint32_t lds = group_lds_bytes(p, small);
+    const uint32_t per_cu = (160u * 1024u) / lds;
+    const uint32_t cap = p.cus * per_cu * kWavesPerGroup;
+    if (cap < n_waves) n_waves = cap;
+    const uint32_t want = n_waves < p.n_tiles ? n_waves : p.n_tiles;
+    dim3 grid((want + kWavesPerGroup - 1) / kWavesPerGroup), block(64 * kWavesPerGroup);
+    const bool mfma = p.use_mfma != 0;
+    if (small && mfma) hipLaunchKernelGGL((render_kernel<false, false, false, true, true, true>), grid, block, lds, st, p);
+    else if (small) hipLaunchKernelGGL((render_kernel<false, false, false, true, false, true>), grid, block, lds, st, p);
+    else if (mfma) hipLaunchKernelGGL((render_kernel<false, false, false, false, true, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((render_kernel<false, false, false, false, false, true>), grid, block, lds, st, p);
     return (int)hipGetLastError();
 }
 

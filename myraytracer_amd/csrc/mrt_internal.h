@@ -77,6 +77,12 @@ struct KParams {
     uint32_t* tile_cost;        // n_tiles: sum of its pixels' loop trips in this frame, or null
     void* pix_acc;              // per local pixel: colour sum of the frame + its cost (16 B), render -> finalize
     unsigned long long* wave_log;  // diagnostic (-DMRT_STAMPS builds): 4 x u64 per wave, or null
+    // mrt_debug_world_hit (the DBG instantiation of render_kernel): rays in (origin xyz, direction xyz), out: winner
+    // {sphere index | -1, bits of t} per ray and the bitmap of spheres that reached the root tests
+    const float* dbg_rays;
+    int32_t* dbg_hit;
+    uint32_t* dbg_cand;
+    uint32_t dbg_words;         // bitmap words per ray
 };
 
 // api.cpp: message behind mrt_last_error(NULL), for failures of entry points that have no context
@@ -87,6 +93,7 @@ void set_global_error(const char* msg);
 int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream);
 // the per-tile finalize pass of a rendered frame: colour sums -> framebuffer, tile costs
 int launch_finalize(const KParams& p, void* stream);
+int launch_debug_world_hit(const KParams& p, uint32_t n_waves, void* stream);
 int render_waves_per_cu(int* out);
 // tile_order.hip: order[] = tile ids sorted by cost[] descending (bucket sort; ties in any order).
 // scratch: 1024 u32.

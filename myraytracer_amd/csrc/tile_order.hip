@@ -8,6 +8,14 @@
 //
 // A bucket sort is enough (ties may land in any order): key = 5-bit exponent | 5-bit
 // mantissa of the cost, 1024 buckets, three tiny launches.
+//
+// The sort of frame n+2's queue runs while frame n+1's persistent render grid owns nearly all of every CU's LDS
+// (157.5 of 160 KB at C3) and 5 of its 8 wave slots per SIMD.  A kernel that needs LDS, or a 1,024-thread
+// workgroup, cannot become resident next to it and stays queued until that grid drains -- and the next render
+// with it (round 1: render n+1 started only ~14 ms before render n ended).  So these kernels use NO LDS, few
+// registers and 256-thread (one wave per SIMD) or single-wave workgroups: they slip in beside the render
+// waves.  Equal costs are common (every pure-sky tile costs exactly spp trips per pixel), so a wave first combines
+// its lanes per bucket with ballots and issues one global atomic per distinct bucket.
 
 #include <hip/hip_runtime.h>
 #include "mrt_internal.h"
@@ -26,57 +34,59 @@ __device__ __forceinline__ uint32_t cost_bucket(uint32_t cost) {
     return key < kBuckets ? key : kBuckets - 1u;
 }
 
-// Equal costs are common (every pure-sky tile costs exactly spp trips per pixel), so global atomics per
-// tile would pile up on one address: both passes first combine a block's 1024 tiles in LDS.
-constexpr uint32_t kTilesPerBlock = 1024;
-
-__global__ void __launch_bounds__(256) tile_hist_kernel(const uint32_t* __restrict__ cost, uint32_t* hist, uint32_t n) {
-    __shared__ uint32_t local[kBuckets];
-    for (uint32_t k = threadIdx.x; k < kBuckets; k += 256) local[k] = 0;
-    __syncthreads();
-    for (uint32_t j = 0; j < kTilesPerBlock / 256; j++) {
-        const uint32_t i = blockIdx.x * kTilesPerBlock + j * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&local[cost_bucket(cost[i])], 1u);
+// Every lane with `valid` adds 1 to counters[bucket] and learns its own position (the counter's value before
+// the wave's addition + its rank among the wave's lanes of the same bucket): one atomic per distinct bucket.
+__device__ __forceinline__ uint32_t wave_bucket_add(uint32_t* counters, uint32_t bucket, bool valid) {
+    uint32_t pos = 0;
+    bool pending = valid;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(pending);
+    while (todo != 0ull) {                                                     // wave-uniform loop
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bucket, leader);
+        const bool mine = pending && bucket == lb;
+        const unsigned long long group = __builtin_amdgcn_ballot_w64(mine);
+        uint32_t base = 0;
+        if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&counters[lb], (uint32_t)__popcll(group));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (mine) {
+            pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(group >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)group, 0u));
+            pending = false;
+        }
+        todo &= ~group;
     }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kBuckets; k += 256)
-        if (local[k]) atomicAdd(&hist[k], local[k]);
+    return pos;
 }
 
-// one block of 1024 threads: hist[b] <- number of tiles in heavier buckets (descending exclusive scan)
-__global__ void __launch_bounds__(1024) tile_scan_kernel(uint32_t* hist) {
-    __shared__ uint32_t s[kBuckets];
-    const uint32_t t = threadIdx.x;
-    s[t] = hist[kBuckets - 1u - t];                    // reversed: index 0 = heaviest bucket
-    __syncthreads();
-    for (uint32_t off = 1; off < kBuckets; off <<= 1) {
-        const uint32_t v = (t >= off) ? s[t - off] : 0u;
-        __syncthreads();
-        s[t] += v;
-        __syncthreads();
+__global__ void __launch_bounds__(256) tile_hist_kernel(const uint32_t* __restrict__ cost, uint32_t* hist, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool ok = i < n;
+    (void)wave_bucket_add(hist, ok ? cost_bucket(cost[i]) : 0u, ok);
+}
+
+// one wave: hist[b] <- number of tiles in heavier buckets (descending exclusive scan); lane l owns the 16
+// buckets 1023 - 16 l ... 1008 - 16 l, heaviest first
+__global__ void __launch_bounds__(64) tile_scan_kernel(uint32_t* hist) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { v[j] = hist[kBuckets - 1u - (16u * lane + (uint32_t)j)]; sum += v[j]; }
+    uint32_t incl = sum;                               // inclusive scan of the lanes' sums
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += up;
     }
-    hist[kBuckets - 1u - t] = (t == 0) ? 0u : s[t - 1u];
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { hist[kBuckets - 1u - (16u * lane + (uint32_t)j)] = run; run += v[j]; }
 }
 
 __global__ void __launch_bounds__(256) tile_scatter_kernel(const uint32_t* __restrict__ cost, uint32_t* offsets,
                                                            uint32_t* __restrict__ order, uint32_t n) {
-    __shared__ uint32_t local[kBuckets];      // count, then this block's base offset, per bucket
-    for (uint32_t k = threadIdx.x; k < kBuckets; k += 256) local[k] = 0;
-    __syncthreads();
-    uint32_t bucket[kTilesPerBlock / 256], rank[kTilesPerBlock / 256];
-    for (uint32_t j = 0; j < kTilesPerBlock / 256; j++) {
-        const uint32_t i = blockIdx.x * kTilesPerBlock + j * 256 + threadIdx.x;
-        bucket[j] = 0; rank[j] = 0;
-        if (i < n) { bucket[j] = cost_bucket(cost[i]); rank[j] = atomicAdd(&local[bucket[j]], 1u); }
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kBuckets; k += 256)
-        if (local[k]) local[k] = atomicAdd(&offsets[k], local[k]);     // reserve this block's range
-    __syncthreads();
-    for (uint32_t j = 0; j < kTilesPerBlock / 256; j++) {
-        const uint32_t i = blockIdx.x * kTilesPerBlock + j * 256 + threadIdx.x;
-        if (i < n) order[local[bucket[j]] + rank[j]] = i;
-    }
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool ok = i < n;
+    const uint32_t pos = wave_bucket_add(offsets, ok ? cost_bucket(cost[i]) : 0u, ok);
+    if (ok) order[pos] = i;
 }
 
 }  // namespace
@@ -86,9 +96,9 @@ int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, 
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(scratch, 0, kBuckets * sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
-    const uint32_t blocks = (n_tiles + kTilesPerBlock - 1u) / kTilesPerBlock;
+    const uint32_t blocks = (n_tiles + 255u) / 256u;
     hipLaunchKernelGGL(tile_hist_kernel, dim3(blocks), dim3(256), 0, st, cost, scratch, n_tiles);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, scratch);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(64), 0, st, scratch);
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, st, cost, scratch, order, n_tiles);
     return (int)hipGetLastError();
 }

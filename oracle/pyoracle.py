@@ -120,6 +120,8 @@ def lib():
                                       C.c_void_p, C.POINTER(CameraRaw), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                       C.POINTER(Counters)]
+        L.orc_world_hit_batch.argtypes = [C.POINTER(World), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -148,6 +150,18 @@ def pack_world(spheres):
     lib().orc_pack_world(_ptr(spheres), n, C.byref(w), _ptr(vec4), C.byref(nv), _ptr(f32), C.byref(nf),
                          _ptr(i32), C.byref(ni))
     return PackedWorld(w, vec4[:nv.value].copy(), f32[:nf.value].copy(), i32[:ni.value].copy())
+
+
+def world_hit_batch(packed, rays, nthreads=0):
+    """world_hit (shader.wgsl:314-329, range [0.001, 1e4)) per ray -> (winner index or -1, t, disc >= 0 matrix [n, spheres])."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n, ns = len(rays), int(packed.world.spheres.length)
+    hit = np.empty(n, np.int32)
+    t = np.empty(n, np.float32)
+    ge0 = np.zeros((n, ns), np.uint8)
+    lib().orc_world_hit_batch(C.byref(packed.world), _ptr(packed.vec4), _ptr(packed.f32), _ptr(packed.i32), _ptr(rays), n,
+                              _ptr(hit), _ptr(t), _ptr(ge0), nthreads)
+    return hit, t, ge0.astype(bool)
 
 
 def fill_seeds(seed, w, h):

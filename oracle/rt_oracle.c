@@ -154,17 +154,24 @@ static inline float sphere_load_radius(const scene_t* s, int32_t idx) {
 
 typedef struct { v3 at; float t; v3 normal; int front_face; int32_t ty, idx; } hit_t;
 
-/* shader.wgsl:270-312 sphere_hit */
-static inline int sphere_hit(const scene_t* s, int32_t idx, v3 orig, v3 dir, float t_min, float t_sup, hit_t* out) {
-    v3 center = sphere_load_center(s, idx);
-    float radius = sphere_load_radius(s, idx);
-
+/* shader.wgsl:274-282: a, b and the discriminant d of sphere_hit (what `if d < 0 { return false }` tests) */
+static inline float sphere_discriminant(v3 center, float radius, v3 orig, v3 dir, float* a_out, float* b_out) {
     v3 oc = v3_sub(orig, center);
     float a = dot3(dir, dir);
     float b = dot3(oc, dir);
     /* c = dot(oc,oc) - radius*radius, MRT-F32 form (see header) */
     float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -(radius * radius))));
-    float d = __builtin_fmaf(b, b, -(a * c));
+    *a_out = a; *b_out = b;
+    return __builtin_fmaf(b, b, -(a * c));
+}
+
+/* shader.wgsl:270-312 sphere_hit */
+static inline int sphere_hit(const scene_t* s, int32_t idx, v3 orig, v3 dir, float t_min, float t_sup, hit_t* out) {
+    v3 center = sphere_load_center(s, idx);
+    float radius = sphere_load_radius(s, idx);
+
+    float a, b;
+    float d = sphere_discriminant(center, radius, orig, dir, &a, &b);
 
     if (d < 0.0f) return 0;
 
@@ -478,6 +485,32 @@ int orc_world_hit(const orc_world* w, const float* vec4, const float* f32, const
     if (hit_sphere) *hit_sphere = which;
     return r;
 }
+/* world_hit (range [0.001, 1e4), shader.wgsl:340) for a batch of rays, plus -- for the tests of the HIP path's conservative
+ * sweep -- which spheres have a discriminant that is not < 0 (the set sphere_hit goes on to take roots of). */
+void orc_world_hit_batch(const orc_world* w, const float* vec4, const float* f32, const int32_t* i32,
+                         const float* rays, int64_t n, int32_t* hit_sphere, float* hit_t_out, uint8_t* disc_ge0, int nthreads) {
+    scene_t s = {w, vec4, f32, i32};
+    const int32_t ns = w->spheres.length;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
+#endif
+    for (int64_t r = 0; r < n; r++) {
+        const v3 o = v3_make(rays[6 * r], rays[6 * r + 1], rays[6 * r + 2]), d = v3_make(rays[6 * r + 3], rays[6 * r + 4], rays[6 * r + 5]);
+        hit_t h; memset(&h, 0, sizeof h);
+        int32_t which = -1;
+        const int got = world_hit(&s, o, d, 0.001f, 1.0e4f, &h, &which);
+        hit_sphere[r] = got ? which : -1;
+        hit_t_out[r] = got ? h.t : 1.0e4f;
+        if (disc_ge0)
+            for (int32_t i = 0; i < ns; i++) {
+                float a, b;
+                const float disc = sphere_discriminant(sphere_load_center(&s, i), sphere_load_radius(&s, i), o, d, &a, &b);
+                disc_ge0[r * ns + i] = !(disc < 0.0f);
+            }
+    }
+}
+
 void orc_color_sky(float y, float out[3]) { v3 c = color_sky(y); out[0] = c.x; out[1] = c.y; out[2] = c.z; }
 
 /* lib.rs:722-799: SoA packing.  vec4 = [centers(x,y,z,1) | lambertian albedos(r,g,b,1) |

@@ -109,6 +109,10 @@ int  orc_world_hit(const orc_world* w, const float* vec4, const float* f32, cons
                    const float orig[3], const float dir[3], float t_min, float t_sup,
                    orc_hit* out, int32_t* hit_sphere);
 void orc_color_sky(float y, float out[3]);
+/* world_hit over [0.001, 1e4) for n rays (6 floats each: origin, direction): hit_sphere[r] = winner or -1, hit_t[r] = its t
+ * (1e4 on a miss); disc_ge0 (optional, n x spheres.length bytes): 1 where sphere_hit's discriminant is not < 0 */
+void orc_world_hit_batch(const orc_world* w, const float* vec4, const float* f32, const int32_t* i32,
+                         const float* rays, int64_t n, int32_t* hit_sphere, float* hit_t, uint8_t* disc_ge0, int nthreads);
 void orc_camera_derive(const orc_camera* cam, orc_camera_raw* out);
 
 /* AoS -> SoA packing of lib.rs:722-799.  spheres: n x {cx,cy,cz,r, ty, p0,p1,p2,p3}
