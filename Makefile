@@ -50,4 +50,4 @@ clean:
 # diagnostic build with s_memtime phase stamps (scripts/phase_profile.py); not the product
 stamps: $(SRCS) $(HDRS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $(LIBDIR)/libmyraytracer_amd_stamps.so $(SRCS)
+	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $(LIBDIR)/libmyraytracer_amd_stamps.so $(SRCS) -ldl

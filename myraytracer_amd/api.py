@@ -417,7 +417,8 @@ def gather(states: Sequence[State], root: int = 0):
     arr = (C.c_void_p * len(states))(*[s._ctx for s in states])
     st = L.mrt_gather(arr, len(states), root)
     if st:
-        raise MrtError(st, "mrt_gather", (L.mrt_last_error(states[root]._ctx) or L.mrt_last_error(None)).decode())
+        ctx = states[root]._ctx if 0 <= root < len(states) else None
+        raise MrtError(st, "mrt_gather", (L.mrt_last_error(ctx) or b"").decode())
 
 
 def shard_global_row(local_row: int, rank: int, world: int) -> int:

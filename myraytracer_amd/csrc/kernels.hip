@@ -539,7 +539,6 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         };
         const bool fresh = live && need_sample;         // pixel acquired in this iteration: nothing to trace or shade yet
         if (live && !fresh) pix_trips++;
-        MRT_STAMP(0);
 
         // ------------------------------------------------------------ world_hit, shader.wgsl:314-329
         const bool trace = live && !fresh && depth_left != 0u;              // lanes inside the loop of :339
@@ -917,6 +916,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             // path for the lanes of either kind
             if (!task_done) d = normalize3(ndir);
         }
+        MRT_STAMP(0);
         if (COUNT) started += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(start_sample));
     }
 

@@ -8,7 +8,8 @@ from myraytracer_amd import _lib
 a = sys.argv[1:]
 scene = a[0] if a else "cover-glass"
 w, h, spp = (int(a[1]), int(a[2]), int(a[3])) if len(a) > 3 else (1920, 1080, 32)
-sp, cam = M.scene_cover(1, scene == "cover-glass") if scene.startswith("cover") else (M.scene_default(), None)
+sp, cam = (M.scene_cover(1, scene == "cover-glass") if scene.startswith("cover") else M.scene_stress(1, 100) if scene == "stress"
+           else (M.scene_default(), None))
 with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     st.set_world(sp)
     if cam is not None: st.set_camera(cam)

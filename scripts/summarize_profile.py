@@ -52,10 +52,28 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         tj[key] = hbm
         tj["_note"] = "HBM bytes per render_kernel launch from rocprofv3 PMC passes; see profiles/*_pmc.json"
         json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
-json.dump(out, open(os.path.join(dst, f"{rnd}_{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+bench_line = None
 for log in ("bench_trace.log",):
     lines = [l for l in open(os.path.join(src, log)) if l.startswith("{")]
     if lines:
         open(os.path.join(dst, f"{rnd}_{tag}_bench_under_rocprof.json"), "w").write(lines[-1])
+        bench_line = json.loads(lines[-1])
+# VALU instructions per wave-iteration of the bounce loop (one world_hit for up to 64 rays): SQ_INSTS_VALU per launch over
+# the launch's wave iterations = world_hit calls / (64 x lane utilisation), both from the bench line of the traced run
+if bench_line and "SQ_INSTS_VALU" in vals and key:
+    v = bench_line["valu"]
+    px_spp = [int(x) for x in key.split("_")[-2].split("x")]
+    hits_per_launch = v["mean_bounces_per_sample"] * px_spp[0] * px_spp[1] * px_spp[2]
+    wave_iters = hits_per_launch / (64.0 * v["lane_utilisation"])
+    out["derived"]["valu_insts_per_wave_bounce"] = vals["SQ_INSTS_VALU"] / wave_iters
+    vj_path = os.path.join(dst, "valu_pmc.json")
+    vj = json.load(open(vj_path)) if os.path.exists(vj_path) else {}
+    vj[key] = {"issue_frac": out["derived"].get("valu_issue_utilisation_at_2cyc_per_inst"),
+               "thread_utilisation": out["derived"].get("valu_thread_utilisation"),
+               "valu_insts_per_wave_bounce": out["derived"]["valu_insts_per_wave_bounce"],
+               "source": f"profiles/{rnd}_{tag}_pmc.json"}
+    vj["_note"] = "SQ counters per render_kernel launch from rocprofv3 --pmc passes of bench.py (scripts/profile.sh); bench.py copies them into valu.pmc_*"
+    json.dump(vj, open(vj_path, "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(dst, f"{rnd}_{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out.get("derived", {}), indent=1))
 print(open(os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv")).read())
