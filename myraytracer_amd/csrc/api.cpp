@@ -68,6 +68,7 @@ void free_frame_buffers(mrt_ctx* c) {
         if (S.d_pix_acc) (void)hipFree(S.d_pix_acc);
         S.d_tile_cost = S.d_tile_order = S.d_sort_scratch = nullptr;
         S.d_pix_acc = nullptr;
+        S.pix_acc_layers = 0; S.blocks = 1;
         S.cost_valid = false;
     }
     c->d_seeds = nullptr; c->d_fb[0] = c->d_fb[1] = nullptr;
@@ -106,6 +107,7 @@ int alloc_frame_buffers(mrt_ctx* c) {
         HIP_TRY(c, hipMalloc(&S.d_sort_scratch, (1024 + 16) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&S.d_pix_acc, (n ? n : 1) * 16));
         HIP_TRY(c, hipMemsetAsync(S.d_pix_acc, 0, (n ? n : 1) * 16, c->stream));
+        S.pix_acc_layers = 1; S.blocks = 1;
         S.cost_valid = false;
     }
     c->inputs_dirty = true;
@@ -971,6 +973,27 @@ int mrt_redraw(mrt_ctx* c) {
     p.tile_queue = S.d_sort_scratch + 1024;
     p.tile_order = nullptr;
     p.tile_cost = S.d_tile_cost;
+    // counter-RNG mode: one layer of colour sums per block of MRT_COUNTER_BLOCK samples; the slot's buffer grows
+    // on demand (a frame of this slot that is still in flight is waited for first)
+    {
+        const uint32_t spp = c->locals.samples_per_frame;
+        uint32_t blocks = 1;
+        if (c->locals.rng_mode == MRT_RNG_COUNTER && spp > MRT_COUNTER_BLOCK) blocks = (spp + MRT_COUNTER_BLOCK - 1) / MRT_COUNTER_BLOCK;
+        const size_t n = local_texels(c) ? local_texels(c) : 1;
+        if ((uint64_t)blocks * n >= (1ull << 32) || (uint64_t)blocks * c->n_tiles >= (1ull << 26))
+            return fail(c, MRT_ERR_INVALID_ARG, "mrt_redraw: %u spp in counter mode over %zu pixels exceeds the tile queue's range", spp, n);
+        if (S.pix_acc_layers < blocks) {
+            HIP_TRY(c, hipStreamSynchronize(S.stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (S.d_pix_acc) (void)hipFree(S.d_pix_acc);
+            S.d_pix_acc = nullptr; S.pix_acc_layers = 0;
+            HIP_TRY(c, hipMalloc(&S.d_pix_acc, (size_t)blocks * n * 16));
+            S.pix_acc_layers = blocks;
+        }
+        S.blocks = blocks;
+        p.n_blocks = blocks;
+        p.pix_stride = (uint32_t)n;
+    }
     p.pix_acc = S.d_pix_acc;
     // side stream: wait for the scene / seeds uploads and for this slot's previous frame (n-2) to
     // have been finalized (its colour sums and tile costs are about to be overwritten / used)
@@ -1031,10 +1054,16 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
     const size_t n = local_texels(c);
     if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_read_pixel_costs: need %zu", n);
     HIP_TRY(c, hipSetDevice(c->device));
-    std::vector<uint32_t> tmp(n * 4);
     HIP_TRY(c, sync_all(c));
-    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->slot[(c->frame_seq + mrt_ctx::kFrameSlots - 1u) % mrt_ctx::kFrameSlots].d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
+    const mrt_ctx::FrameSlot& S = c->slot[(c->frame_seq + mrt_ctx::kFrameSlots - 1u) % mrt_ctx::kFrameSlots];
+    std::vector<uint32_t> tmp(n * 4), layer(n * 4);
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), S.d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t b = 1; b < S.blocks; b++) {       // counter mode: a pixel's cost is the sum over its blocks
+        HIP_TRY(c, hipMemcpyAsync(layer.data(), (const char*)S.d_pix_acc + (size_t)b * n * 16, n * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; i++) tmp[4 * i + 3] += layer[4 * i + 3];
+    }
     for (size_t i = 0; i < n; i++) out[i] = tmp[4 * i + 3];
     return MRT_OK;
 }

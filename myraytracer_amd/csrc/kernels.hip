@@ -328,6 +328,7 @@ struct alignas(16) PixAcc { float r, g, b; uint32_t cost; };
 //    until the slowest pixel of its tile is done;
 //  * finished colour sums are left in HBM; finalize_kernel turns them into the framebuffer with
 //    coalesced whole-line stores.
+constexpr uint32_t kCtrBlock = MRT_COUNTER_BLOCK;   // counter-RNG mode: samples per separately summed block
 constexpr uint32_t kRingCap = 128;        // < 64 waiting + 64 from a new tile; power of two
 
 // Kernel arguments that are only needed between sweeps (camera, material tables, queue and
@@ -382,9 +383,14 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.clusters;
     const float pixel_side = 2.0f / (float)H;                 // fs_main :373
 
-    // pixel id q = (tile << 6) | lane-in-tile -> coordinates
-    auto locate = [&](KArgPtr C, uint32_t q, uint32_t& px, uint32_t& py, uint32_t& texel) -> bool {
-        const uint32_t tile = q >> 6, l = q & 63u;
+    // pixel id q = (virtual tile << 6) | lane-in-tile -> coordinates.  In the counter-RNG mode a frame is n_blocks LAYERS
+    // of the image (layer b = samples [64 b, 64 b + 64) of every pixel, summed separately: the samples of a pixel are
+    // independent there), and virtual tile = layer * n_tiles + tile; otherwise there is one layer.
+    auto locate = [&](KArgPtr C, uint32_t q, uint32_t& px, uint32_t& py, uint32_t& texel, uint32_t& layer) -> bool {
+        uint32_t tile = q >> 6;
+        const uint32_t l = q & 63u;
+        layer = 0u;
+        if (CTR && !PILOT) { layer = tile / C->n_tiles; tile -= layer * C->n_tiles; }
         const uint32_t tile_x = tile % C->tiles_x, band = tile / C->tiles_x;
         const uint32_t Wc = C->locals.shape[0], Hc = C->locals.shape[1];
         px = tile_x * kTileW + (l & 7u);
@@ -401,7 +407,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     uint32_t s_done = 0, pix_trips = 0, texel = 0;
     float base_x = 0.0f, base_y = 0.0f;
     Rng rng; rng.draws = 0; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    uint32_t base0 = 0, base1 = 0, base2 = 0, base3 = 0;     // CTR: the pixel's frame state, hashed per sample
+    uint32_t blk = 0;                                         // CTR: (layer << 7) | samples in this lane's block (<= 64)
     V3 color = v3(0.0f, 0.0f, 0.0f);
     V3 o = v3(0.0f, 0.0f, 0.0f), d = v3(0.0f, 0.0f, -1.0f), att = v3(1.0f, 1.0f, 1.0f);
     uint32_t depth_left = 0, trips = 0;
@@ -421,7 +427,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         if (release) {
             if (!DBG) {
                 PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
-                reinterpret_cast<PixAcc*>(cold_args()->pix_acc)[texel] = sa;
+                const KArgPtr C = cold_args();
+                reinterpret_cast<PixAcc*>(C->pix_acc)[(CTR ? (size_t)(blk >> 7) * C->pix_stride : (size_t)0) + texel] = sa;
             }
             has_task = false;
         }
@@ -432,13 +439,16 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(C->tile_queue, 1u);
             t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= C->n_tiles) {
+            const uint32_t n_layers = (CTR && !PILOT) ? C->n_blocks : 1u;
+            if (t >= C->n_tiles * n_layers) {
                 queue_empty = true;
             } else {
-                const uint32_t tile = C->tile_order ? C->tile_order[t] : t;
-                uint32_t fx, fy, ft;
+                // layer by layer, each in the heaviest-first order of the tiles
+                const uint32_t lay = (CTR && !PILOT) ? t / C->n_tiles : 0u, ti = t - lay * C->n_tiles;
+                const uint32_t tile = lay * C->n_tiles + (C->tile_order ? C->tile_order[ti] : ti);
+                uint32_t fx, fy, ft, fl;
                 const uint32_t fq = (tile << 6) | lane;
-                const bool ok = locate(C, fq, fx, fy, ft);
+                const bool ok = locate(C, fq, fx, fy, ft, fl);
                 const unsigned long long m = __ballot(ok);
                 if (ok) ring[(tail + rank_in(m)) & (kRingCap - 1u)] = fq;
                 const uint32_t nf = (uint32_t)__popcll(m);
@@ -452,8 +462,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             const bool take = !has_task && rk < avail;
             if (take) {
                 const KArgPtr C = cold_args();
-                uint32_t px, py;
-                locate(C, ring[(head + rk) & (kRingCap - 1u)], px, py, texel);
+                uint32_t px, py, layer;
+                locate(C, ring[(head + rk) & (kRingCap - 1u)], px, py, texel, layer);
                 const float Wf = (float)C->locals.shape[0], Hf = (float)C->locals.shape[1];
                 base_x = (((float)px + 0.5f) - 0.5f * Wf) * pixel_side;            // fs_main :374
                 base_y = (((float)py + 0.5f) - 0.5f * Hf) * pixel_side;
@@ -462,11 +472,15 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 rng.s1 = sd.y ^ C->locals.rng_shuffle[1];
                 rng.s2 = sd.z ^ C->locals.rng_shuffle[2];
                 rng.s3 = sd.w ^ C->locals.rng_shuffle[3];
-                if (CTR) { base0 = rng.s0; base1 = rng.s1; base2 = rng.s2; base3 = rng.s3; }
                 color = v3(0.0f, 0.0f, 0.0f);                                         // :376
                 s_done = 0;
                 pix_trips = 0;
                 has_task = true;
+                if (CTR) {      // this lane's block of the pixel's samples
+                    const uint32_t first = layer * kCtrBlock;
+                    const uint32_t cnt = spp > first ? (spp - first < kCtrBlock ? spp - first : kCtrBlock) : 0u;
+                    blk = (layer << 7) | cnt;
+                }
                 task_done = (spp == 0u);                // nothing to draw: colour 0/0, as the reference
                 need_sample = !task_done;
                 if (DBG) {
@@ -498,11 +512,15 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         // ray.  Per lane the draw order is the reference's: jitter, lens, then the path's draws.
         auto new_sample = [&](V3& nd) {
             if (CTR) {      // extension: this sample's state = hash(pixel frame state, sample index)
-                const uint32_t k4 = 4u * s_done;
-                rng.s0 = fmix32(base0 + 0x9E3779B9u * (k4 + 1u));
-                rng.s1 = fmix32(base1 + 0x9E3779B9u * (k4 + 2u));
-                rng.s2 = fmix32(base2 + 0x9E3779B9u * (k4 + 3u));
-                rng.s3 = fmix32(base3 + 0x9E3779B9u * (k4 + 4u));
+                // (the pixel's frame state -- seed texel ^ shuffle, :44-47 -- is re-read per sample rather than held in
+                // four more registers across the whole bounce loop)
+                const KArgPtr Cs = cold_args();
+                const uint4 sd = reinterpret_cast<const uint4*>(Cs->seeds)[texel];
+                const uint32_t k4 = 4u * ((blk >> 7) * kCtrBlock + s_done);     // the sample's index within the frame
+                rng.s0 = fmix32((sd.x ^ Cs->locals.rng_shuffle[0]) + 0x9E3779B9u * (k4 + 1u));
+                rng.s1 = fmix32((sd.y ^ Cs->locals.rng_shuffle[1]) + 0x9E3779B9u * (k4 + 2u));
+                rng.s2 = fmix32((sd.z ^ Cs->locals.rng_shuffle[2]) + 0x9E3779B9u * (k4 + 3u));
+                rng.s3 = fmix32((sd.w ^ Cs->locals.rng_shuffle[3]) + 0x9E3779B9u * (k4 + 4u));
                 if ((rng.s0 | rng.s1 | rng.s2 | rng.s3) == 0u) {
                     rng.s0 = 0x9E3779B9u; rng.s1 = 0x7F4A7C15u; rng.s2 = 0xBF58476Du; rng.s3 = 0x1CE4E5B9u;
                 }
@@ -906,7 +924,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             if (path_done) {
                 color = color + contrib;                                    // :381
                 s_done++;
-                if (s_done < spp) start_sample = true; else task_done = true;
+                if (s_done < (CTR ? (blk & 127u) : spp)) start_sample = true; else task_done = true;
             }
             if (start_sample) {
                 new_sample(ndir);
@@ -960,7 +978,13 @@ __global__ void __launch_bounds__(64) finalize_kernel(const KParams P) {
     const size_t texel = (size_t)(band * kBandRows + (lane >> 3)) * W + px;
     uint32_t cost = 0;
     if (px < W && py < H) {
-        const PixAcc sa = reinterpret_cast<const PixAcc*>(P.pix_acc)[texel];
+        PixAcc sa = reinterpret_cast<const PixAcc*>(P.pix_acc)[texel];
+        // counter-RNG mode: the pixel's blocks of 64 samples were summed separately (possibly by different lanes);
+        // their sums are added in block order -- ((S0 + S1) + S2) ... -- which is how the mode defines the colour
+        for (uint32_t b = 1; b < (PILOT ? 1u : P.n_blocks); b++) {
+            const PixAcc sb = reinterpret_cast<const PixAcc*>(P.pix_acc)[(size_t)b * P.pix_stride + texel];
+            sa.r += sb.r; sa.g += sb.g; sa.b += sb.b; sa.cost += sb.cost;
+        }
         cost = sa.cost;
         if (!PILOT) {
             const float n = (float)P.locals.samples_per_frame;

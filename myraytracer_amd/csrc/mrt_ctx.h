@@ -54,7 +54,9 @@ struct mrt_ctx {
     struct FrameSlot {
         hipStream_t stream = nullptr;
         hipEvent_t render_done = nullptr, finalize_done = nullptr;
-        void* d_pix_acc = nullptr;             // per-pixel colour sums + costs, render -> finalize
+        void* d_pix_acc = nullptr;             // per-pixel (x per-block, counter mode) colour sums + costs, render -> finalize
+        size_t pix_acc_layers = 0;             // capacity in layers of local_texels entries
+        uint32_t blocks = 1;                   // layers the slot's most recent frame used
         uint32_t* d_tile_cost = nullptr;       // written by this slot's finalize, orders its next queue
         uint32_t* d_tile_order = nullptr;
         uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter

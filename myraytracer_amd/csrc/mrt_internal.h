@@ -75,7 +75,10 @@ struct KParams {
     uint32_t tiles_x, n_tiles;  // tiles per band row; tiles in this shard
     uint32_t pilot_spp;         // samples per pixel of the cost-estimating pilot launch
     uint32_t* tile_cost;        // n_tiles: sum of its pixels' loop trips in this frame, or null
-    void* pix_acc;              // per local pixel: colour sum of the frame + its cost (16 B), render -> finalize
+    void* pix_acc;              // per local pixel (and per block of samples): colour sum + cost (16 B), render -> finalize
+    // counter-RNG mode: a pixel's samples are independent, so the frame is n_blocks layers (block b = samples
+    // [64 b, 64 b + 64)), each summed into pix_acc[b * pix_stride + texel]; finalize adds the layers in order.  1 otherwise.
+    uint32_t n_blocks, pix_stride;
     unsigned long long* wave_log;  // diagnostic (-DMRT_STAMPS builds): 4 x u64 per wave, or null
     // mrt_debug_world_hit (the DBG instantiation of render_kernel): rays in (origin xyz, direction xyz), out: winner
     // {sphere index | -1, bits of t} per ray and the bitmap of spheres that reached the root tests

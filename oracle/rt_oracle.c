@@ -380,15 +380,29 @@ static void shade_pixel(const orc_locals* L, const scene_t* s, const orc_camera_
 
     uint32_t base[4];
     for (int k = 0; k < 4; k++) base[k] = rng.s[k];
-    v3 color = v3_make(0.0f, 0.0f, 0.0f);
+    /* The reference's stream mode adds the samples one by one (:376-382).  In the counter mode (extension) the samples
+     * are independent, and the sum is DEFINED blockwise so that a pixel's blocks can be rendered by different lanes:
+     * colour = (..((S_0 + S_1) + S_2) ..), S_b = the sequential sum of samples [b*B, min(spp, (b+1)*B)), B = ORC_COUNTER_BLOCK.
+     * Up to B samples per frame that is the same expression as the stream mode's. */
+    const int counter = L->rng_mode == ORC_RNG_COUNTER;
+    v3 color = v3_make(0.0f, 0.0f, 0.0f), block = v3_make(0.0f, 0.0f, 0.0f);
     for (uint32_t i = 0; i < L->samples_per_frame; i++) {                          /* :378 */
-        if (L->rng_mode == ORC_RNG_COUNTER) orc_sample_state(base, i, rng.s);      /* extension, see header */
+        if (counter) orc_sample_state(base, i, rng.s);                             /* extension, see header */
         float u = rand_f32(&rng); float v = rand_f32(&rng);                        /* :71-75 */
         float vx = base_x + u * pixel_side;                                        /* :379-380 */
         float vy = base_y + v * pixel_side;
         v3 orig, dir;
         camera_ray(cam, vx, vy, &rng, &orig, &dir);
-        color = v3_add(color, color_world(s, orig, dir, L->ray_depth, &rng, c));   /* :381 */
+        const v3 sample = color_world(s, orig, dir, L->ray_depth, &rng, c);        /* :381 */
+        if (!counter) {
+            color = v3_add(color, sample);
+        } else {
+            block = v3_add(block, sample);
+            if ((i + 1u) % ORC_COUNTER_BLOCK == 0u || i + 1u == L->samples_per_frame) {
+                color = (i < ORC_COUNTER_BLOCK) ? block : v3_add(color, block);    /* the first block IS the running sum */
+                block = v3_make(0.0f, 0.0f, 0.0f);
+            }
+        }
         c->samples++;
     }
     float n = (float)L->samples_per_frame;

@@ -66,6 +66,7 @@ typedef struct {
     uint32_t _pad[2];
 } orc_locals;
 enum { ORC_RNG_PIXEL_STREAM = 0, ORC_RNG_COUNTER = 1 };
+#define ORC_COUNTER_BLOCK 64u   /* counter mode: samples are summed in blocks of 64, the blocks' sums in index order */
 
 /* user-level camera (extension; mode 0 = the fixed pinhole of shader.wgsl:360-381) */
 typedef struct {

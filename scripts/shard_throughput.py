@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
-"""Dev helper (GPU box): pipelined throughput of ONE rank's share of a multi-GPU bench workload."""
+"""Dev helper (GPU box): pipelined throughput and lane utilisation of ONE rank's share of a multi-GPU workload.
+   scripts/shard_throughput.py <scene: cover-glass|stress> <w> <h> <spp> <rank> <world> [frames] [rng_mode 0|1]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import myraytracer_amd as M
-w, h, spp, rank, world = (int(x) for x in sys.argv[1:6])
-K = int(sys.argv[6]) if len(sys.argv) > 6 else 4
-sp, cam = M.scene_cover(1, True)
+scene = sys.argv[1]
+w, h, spp, rank, world = (int(x) for x in sys.argv[2:7])
+K = int(sys.argv[7]) if len(sys.argv) > 7 else 4
+mode = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+sp, cam = M.scene_stress(1, 100) if scene == "stress" else M.scene_cover(1, True)
 with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 1 else None) as st:
+    from myraytracer_amd import _lib
     if os.environ.get("MRT_SWEEP"):       # 1 = SGPR-fed VALU sweep, 2 = matrix-core sweep
-        from myraytracer_amd import _lib
         assert _lib.load().mrt_debug_set_sweep(st._ctx, int(os.environ["MRT_SWEEP"])) == 0
     if os.environ.get("MRT_HIER"):        # "max_levels,top_target"
-        from myraytracer_amd import _lib
         h_ = [int(x) for x in os.environ["MRT_HIER"].split(",")]
         assert _lib.load().mrt_debug_set_hierarchy(st._ctx, h_[0], h_[1]) == 0
     if os.environ.get("MRT_CLUSTER"):
-        from myraytracer_amd import _lib
         _lib.load().mrt_debug_set_cluster_factor(st._ctx, float(os.environ["MRT_CLUSTER"]))
-    st.set_world(sp); st.set_camera(cam); st.render(2); st.sync()
+    st.set_world(sp); st.set_camera(cam); st.set_rng_mode(mode)
+    st.render(2); st.sync()
+    c0 = st.read_counters()
     t0 = time.perf_counter(); st.render(K); st.sync(); dt = time.perf_counter() - t0
-    print(f"{w}x{h}x{spp} shard {rank}/{world}: {dt / K * 1e3:.1f} ms/frame, per-GPU {w * h * spp / world * K / dt * 1e-6:.1f} Msamples/s, "
-          f"kernel ms {[round(x) for x in st.kernel_ms_history(K)]}")
+    c1 = st.read_counters()
+    util = (c1["world_hit_calls"] - c0["world_hit_calls"]) / max(1, c1["lane_slots"] - c0["lane_slots"])
+    print(f"{scene} {w}x{h}x{spp} shard {rank}/{world} rng_mode {mode}: {dt / K * 1e3:.1f} ms/frame, per-GPU "
+          f"{w * h * spp / world * K / dt * 1e-6:.1f} Msamples/s, lane utilisation {util:.3f}, "
+          f"kernel ms {[round(x) for x in st.kernel_ms_history(K)]}", flush=True)

@@ -4,7 +4,7 @@ every framebuffer word must match; north_star's tolerance (RMSE < 1e-4) is asser
 import numpy as np
 import pytest
 
-from common import gpu_render, mismatch_report, oracle_render, rmse_rgb
+from common import gpu_render, mismatch_report, oracle_render, rmse_rgb, to_oracle_camera, to_oracle_spheres
 
 pytestmark = pytest.mark.gpu
 
@@ -91,3 +91,61 @@ def test_counter_rng_mode(mrt, oracle, scene):
     other, _, _ = gpu_render(mrt, sc, cam, *args, seed=2, frames=2, rng_mode=0)
     assert not np.array_equal(other, got)
     assert rmse_rgb(other, got) < 0.2          # same picture, different noise
+
+
+@pytest.mark.parametrize("spp", [63, 64, 65, 128, 200, 517])
+def test_counter_mode_blocks_of_64_samples(mrt, oracle, spp):
+    """Counter mode beyond 64 spp: a pixel's samples are summed in blocks of MRT_COUNTER_BLOCK = 64 -- possibly by different
+    lanes -- and the blocks' sums are added in order; the oracle defines the same expression.  Ragged last blocks,
+    exactly-full blocks, two pipelined frames, the per-pixel cost summed over blocks."""
+    sc, cam = mrt.scene_cover(1, True)
+    w, h, depth = 40, 24, 50
+    cnt = oracle.Counters()
+    ref = oracle_render(oracle, sc, cam, w, h, spp, depth, seed=6, frames=2, counters=cnt, rng_mode=1)
+    with mrt.State(mrt.Args(w, h, spp, depth), seed=6) as st:
+        st.set_world(sc)
+        st.set_camera(cam)
+        st.set_rng_mode(1)
+        st.redraw()
+        st.redraw()
+        st.sync()
+        got, c, costs = st.read_framebuffer(), st.read_counters(), st.debug_read_pixel_costs()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    assert c["samples"] == 2 * w * h * spp and c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
+    # costs are those of the LAST frame only: a single-frame oracle pass with frame 1's shuffle
+    one = oracle.Counters()
+    packed = oracle.pack_world(to_oracle_spheres(oracle, sc))
+    oracle.render_frame(w, h, spp, depth, packed, to_oracle_camera(oracle, cam), oracle.fill_seeds(6, w, h),
+                        shuffle=oracle.frame_shuffle(6, 1), counters=one, rng_mode=1)
+    assert int(costs.sum()) == one.world_hit_calls
+
+
+def test_counter_mode_large_scene_and_shards(mrt, oracle):
+    """Counter mode with the large-scene data layout (members from L2, u32 work items: 3,000 spheres) and several
+    blocks; and a 2-way shard of the same frame equals the unsharded one (blocks x bands)."""
+    rng = np.random.default_rng(5)
+    sc = np.zeros(3001, mrt.SPHERE_DTYPE)
+    sc["center"][:3000] = (rng.uniform(-6, 6, (3000, 3)) * [1, 0.1, 1] + [0, 0.2, -8]).astype(np.float32)
+    sc["radius"][:3000] = rng.uniform(0.03, 0.15, 3000).astype(np.float32)
+    sc["material_ty"][:3000] = rng.choice([1, 2, 3], 3000, p=[0.7, 0.2, 0.1])
+    sc["albedo"][:3000] = rng.uniform(0.2, 0.9, (3000, 3)).astype(np.float32)
+    sc["param"][:3000] = np.where(sc["material_ty"][:3000] == 3, 1.5, rng.uniform(0, 0.4, 3000)).astype(np.float32)
+    sc["center"][3000] = (0, -1000, -8); sc["radius"][3000] = 999.9; sc["material_ty"][3000] = 1; sc["albedo"][3000] = 0.5
+    w, h, spp, depth = 48, 32, 150, 12
+    ref = oracle_render(oracle, sc, None, w, h, spp, depth, seed=3, rng_mode=1)
+    got, c, _ = gpu_render(mrt, sc, None, w, h, spp, depth, seed=3, rng_mode=1)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    for sweep in (1, 2):
+        with mrt.State(mrt.Args(w, h, spp, depth), seed=3) as st:
+            st.debug_set_sweep(sweep)
+            st.set_world(sc)
+            st.set_rng_mode(1)
+            st.redraw()
+            again = st.read_framebuffer()
+        assert np.array_equal(again.view(np.uint32), ref.view(np.uint32)), f"sweep variant {sweep}"
+    for rank in (0, 1):
+        part, _, _ = gpu_render(mrt, sc, None, w, h, spp, depth, seed=3, rng_mode=1, shard=(rank, 2))
+        for lr in range(0, part.shape[0], 8):
+            g = mrt.shard_global_row(lr, rank, 2)
+            if g < h:
+                assert np.array_equal(part[lr:lr + 8].view(np.uint32), ref[g:g + 8].view(np.uint32)), (rank, g)
