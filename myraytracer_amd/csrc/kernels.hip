@@ -228,9 +228,9 @@ __device__ __forceinline__ MfmaRay mfma_ray_operands(V3 o, V3 ds) {
     return m;
 }
 // one tile of 32 records against the wave's 64 rays; `a` = this lane's 8 bf16 of the tile's A operand
-// (api.cpp, build_top_mfma).  mA / mB: candidate masks (record i of the chunk at bit 15 - i) of the tile's two
-// chunks for this lane's own ray.
-__device__ __forceinline__ void mfma_sweep_tile(const u32x4 a, const MfmaRay& m, uint32_t& mA, uint32_t& mB) {
+// (api.cpp, build_top_mfma).  Returns the candidate mask of the tile's 32 records (record i at bit 31 - i) for this
+// lane's own ray.
+__device__ __forceinline__ uint32_t mfma_sweep_tile(const u32x4 a, const MfmaRay& m) {
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bf16x8 av = __builtin_bit_cast(bf16x8, a);
     uint32_t hb[2];
@@ -248,12 +248,11 @@ __device__ __forceinline__ void mfma_sweep_tile(const u32x4 a, const MfmaRay& m,
         hb[h] = bb;
     }
     const auto r = __builtin_amdgcn_permlane32_swap(hb[0], hb[1], false, false);
-    mA = r[0] & 0xFFFFu;
-    mB = r[1] & 0xFFFFu;
+    return (r[0] << 16) | (r[1] & 0xFFFFu);            // record i of the tile at bit 31 - i
 }
 
-// Candidate masks: per wave kBlockChunks x 64 lanes of u16 (one 16-sphere sign mask per chunk
-// and lane), chunk-major so that the 64 lanes of one access touch 128 consecutive bytes.
+// Candidate masks: per wave kBlockChunks / 2 x 64 lanes of u32 (one sign mask per 32 records -- two chunks, one
+// matrix-core tile -- and lane), word-major so that the 64 lanes of one access touch 256 consecutive bytes.
 // Diagnostic build only (-DMRT_STAMPS, scripts/phase_profile.py): s_memtime shares of the
 // phases of the bounce loop, summed per wave into counters[4..].  Never in the product .so.
 #ifdef MRT_STAMPS
@@ -365,7 +364,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     unsigned long long* const best_slots = reinterpret_cast<unsigned long long*>(wlds + lds_off_rays()) + 3;   // slot of lane l at [4*l]
     uint32_t* const ring = reinterpret_cast<uint32_t*>(wlds + lds_off_ring());     // FIFO of waiting pixels: tile << 6 | lane-in-tile
     entry_t* const queues = reinterpret_cast<entry_t*>(wlds + lds_off_queues());   // queue k at k * kQueueCap
-    uint16_t* const masks = reinterpret_cast<uint16_t*>(wlds + lds_off_masks(SMALL, levels, P.gen_cap)) + lane;   // chunk c at masks[c*64]
+    uint32_t* const masks = reinterpret_cast<uint32_t*>(wlds + lds_off_masks(SMALL, levels, P.gen_cap)) + lane;   // records 32 w .. 32 w + 31 of the block at masks[w*64]
     if (SMALL) {
         SphereRec* const dst = reinterpret_cast<SphereRec*>(lds_raw);
         const uint32_t n_rec = P.n_nodes;
@@ -595,7 +594,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     const float bq = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));
                     const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, nr2)));
                     const float disc = __builtin_fmaf(bq, bq, -(a * cq));
-                    const bool hq = usable && !(disc < 0.0f);
+                    // (not queued when the sphere is entirely behind the origin: see the node rounds)
+                    const bool hq = usable && !(disc < 0.0f) && ((__float_as_uint(bq) | __float_as_uint(cq)) >> 31) != 0u;
                     const unsigned long long mk = __builtin_amdgcn_ballot_w64(hq);
                     if (hq) queues[n_hits0 + rank_in(mk)] = (entry_t)((lane << kIdBits) | (C->direct_first + j));
                     n_hits0 += (uint32_t)__popcll(mk);
@@ -608,18 +608,16 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             if (MFMA) mr = mfma_ray_operands(v3(o.x - P.mfma_origin[0], o.y - P.mfma_origin[1], o.z - P.mfma_origin[2]), ds);
             for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
                 const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
-                uint32_t nz = 0;                                        // bit c: chunk c of this block has a candidate
+                uint32_t nz = 0;                                        // bit w: records 32 w .. 32 w + 31 of this block hold a candidate
                 uint32_t rem = 0;                                       // this lane's candidate clusters in the block
                 if (MFMA) {
-                    // 32 records per tile = two 16-record chunks per lane and ray
-                    uint32_t c = 0;
-                    for (uint32_t i = blk; i < blk_end; i += 2u * kChunk, c += 2u) {
-                        uint32_t mA, mB;
-                        mfma_sweep_tile(reinterpret_cast<const u32x4*>(P.top_mfma)[(size_t)(i / 32u) * 64u + lane], mr, mA, mB);
-                        masks[c * 64u] = (uint16_t)mA;
-                        masks[(c + 1u) * 64u] = (uint16_t)mB;
-                        nz |= ((mA < 1u ? mA : 1u) << c) | ((mB < 1u ? mB : 1u) << (c + 1u));
-                        rem += (uint32_t)__builtin_popcount(mA | (mB << 16));
+                    // 32 records per tile = one mask word per lane and ray
+                    uint32_t w = 0;
+                    for (uint32_t i = blk; i < blk_end; i += 2u * kChunk, w++) {
+                        const uint32_t m = mfma_sweep_tile(reinterpret_cast<const u32x4*>(P.top_mfma)[(size_t)(i / 32u) * 64u + lane], mr);
+                        masks[w * 64u] = m;
+                        nz |= (m < 1u ? m : 1u) << w;
+                        rem += (uint32_t)__builtin_popcount(m);
                     }
                 } else {
                 // the 64 record SGPRs are live only during the block's sweep, not during its walk
@@ -628,17 +626,19 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 asm volatile("" : "=s"(gb.lo), "=s"(gb.hi));   // defined (uniform) on every path to the block's final wait
                 uint32_t c = 0;
                 for (uint32_t i = blk; i < blk_end; i += kChunk, c++) {
-                    // the record count is padded to 8, not 16: the very last chunk may hold one group only
-                    const bool full = i + 8u < n_padded;
-                    smem_wait_then_load8(ga, gb, sph_quads, full ? i + 8u : 0u, bits);  test8(ga, o, ds, bits);
+                    // (the record count is a multiple of 32 -- api.cpp pads the top level to whole matrix-core tiles --
+                    // so every chunk is full and chunks come in pairs)
+                    smem_wait_then_load8(ga, gb, sph_quads, i + 8u, bits);  test8(ga, o, ds, bits);
                     const uint32_t nxt = (i + kChunk < n_padded) ? i + kChunk : 0u;   // next chunk, or a harmless reload
                     smem_wait_then_load8(gb, ga, sph_quads, nxt, bits);
-                    if (full) test8(gb, o, ds, bits);
-                    // 16 (or 8) signs, record i at bit 15; candidate = S >= 0
-                    const uint32_t m = full ? (~bits & 0xFFFFu) : ((~bits & 0xFFu) << 8);
-                    masks[c * 64u] = (uint16_t)m;
-                    nz |= (m < 1u ? m : 1u) << c;
-                    rem += (uint32_t)__builtin_popcount(m);
+                    test8(gb, o, ds, bits);
+                    if (c & 1u) {
+                        // 32 signs, record i - 16 (the even chunk's first) at bit 31; candidate = S >= 0
+                        const uint32_t m = ~bits;
+                        masks[(c >> 1) * 64u] = m;
+                        nz |= (m < 1u ? m : 1u) << (c >> 1);
+                        rem += (uint32_t)__builtin_popcount(m);
+                    }
                 }
                 // the last prefetch is never consumed, but its destination SGPRs must stay reserved
                 // until it has landed
@@ -673,14 +673,14 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                             const uint32_t room = gen_cap - n_top;
                             const uint32_t n_new = total_rem < room ? total_rem : room;
                             entry_t* const dst = queues + levels * kQueueCap + n_top;
-                            // wm: the chunk mask being unpacked, in the TOP 16 bits (clz = record within the chunk);
-                            // ebase: owner bits | first record id of that chunk
+                            // wm: the 32-record mask word being unpacked (clz = record within the word);
+                            // ebase: owner bits | first record id of that word
                             entry_t* wp = dst + excl;
                             auto refill = [&]() {
                                 const uint32_t cc = (uint32_t)__builtin_ctz(nz);
                                 nz &= nz - 1u;
-                                wm = (uint32_t)masks[cc * 64u] << 16;
-                                ebase = (lane << kIdBits) | (blk + cc * kChunk);
+                                wm = masks[cc * 64u];
+                                ebase = (lane << kIdBits) | (blk + cc * 2u * kChunk);
                             };
                             if (total_rem <= room) {             // the usual case: everything fits, no bound to watch
                                 while ((nz | wm) != 0u) {
@@ -747,7 +747,13 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                 const float bq = __builtin_fmaf(ocz, re.z, __builtin_fmaf(ocy, re.y, ocx * re.x));
                                 const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sr[q].neg_r2)));
                                 const float disc = __builtin_fmaf(bq, bq, -(ra_eff * cq));
-                                h[q] = !(disc < 0.0f);
+                                // A child whose sphere lies entirely behind the ray's origin -- origin outside it (cq >= 0)
+                                // and its centre not ahead (bq >= 0): then sqrt(disc) <= bq, both roots of :290-292 are <= 0
+                                // and fail t >= 0.001 (:291) -- can never be the hit; for a bound (1.5 % larger than what it
+                                // encloses) the same holds for everything inside it.  Dropping it here saves its root test /
+                                // its subtree; it does not change the winner.  Sign bits: both >= +0.
+                                const bool ahead = ((__float_as_uint(bq) | __float_as_uint(cq)) >> 31) != 0u;
+                                h[q] = !(disc < 0.0f) && ahead;
                             }
                         }
                         uint32_t dn = 0;

@@ -153,7 +153,8 @@ def pack_world(spheres):
 
 
 def world_hit_batch(packed, rays, nthreads=0):
-    """world_hit (shader.wgsl:314-329, range [0.001, 1e4)) per ray -> (winner index or -1, t, disc >= 0 matrix [n, spheres])."""
+    """world_hit (shader.wgsl:314-329, range [0.001, 1e4)) per ray -> (winner index or -1, t, disc >= 0 matrix [n, spheres],
+    the same restricted to spheres not entirely behind the ray's origin)."""
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
     n, ns = len(rays), int(packed.world.spheres.length)
     hit = np.empty(n, np.int32)
@@ -161,7 +162,7 @@ def world_hit_batch(packed, rays, nthreads=0):
     ge0 = np.zeros((n, ns), np.uint8)
     lib().orc_world_hit_batch(C.byref(packed.world), _ptr(packed.vec4), _ptr(packed.f32), _ptr(packed.i32), _ptr(rays), n,
                               _ptr(hit), _ptr(t), _ptr(ge0), nthreads)
-    return hit, t, ge0.astype(bool)
+    return hit, t, (ge0 & 1).astype(bool), (ge0 & 2).astype(bool)
 
 
 def fill_seeds(seed, w, h):

@@ -519,8 +519,16 @@ void orc_world_hit_batch(const orc_world* w, const float* vec4, const float* f32
         if (disc_ge0)
             for (int32_t i = 0; i < ns; i++) {
                 float a, b;
-                const float disc = sphere_discriminant(sphere_load_center(&s, i), sphere_load_radius(&s, i), o, d, &a, &b);
-                disc_ge0[r * ns + i] = !(disc < 0.0f);
+                const v3 ctr = sphere_load_center(&s, i);
+                const float rad = sphere_load_radius(&s, i);
+                const float disc = sphere_discriminant(ctr, rad, o, d, &a, &b);
+                /* bit 0: discriminant not < 0.  bit 1: additionally the sphere is not entirely behind the origin, i.e. NOT
+                 * (b >= +0 and c >= +0) -- with both non-negative, sqrt(d) <= b and neither root of :290-292 reaches t_min. */
+                const v3 oc = v3_sub(o, ctr);
+                const float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -(rad * rad))));
+                uint32_t bb, cb; memcpy(&bb, &b, 4); memcpy(&cb, &c, 4);
+                const int ge0 = !(disc < 0.0f), ahead = ((bb | cb) >> 31) != 0u;
+                disc_ge0[r * ns + i] = (uint8_t)(ge0 | ((ge0 && ahead) << 1));
             }
     }
 }

@@ -111,7 +111,8 @@ int  orc_world_hit(const orc_world* w, const float* vec4, const float* f32, cons
                    orc_hit* out, int32_t* hit_sphere);
 void orc_color_sky(float y, float out[3]);
 /* world_hit over [0.001, 1e4) for n rays (6 floats each: origin, direction): hit_sphere[r] = winner or -1, hit_t[r] = its t
- * (1e4 on a miss); disc_ge0 (optional, n x spheres.length bytes): 1 where sphere_hit's discriminant is not < 0 */
+ * (1e4 on a miss); disc_ge0 (optional, n x spheres.length bytes): bit 0 = sphere_hit's discriminant is not < 0, bit 1 = that AND
+ * the sphere is not entirely behind the ray's origin (b >= +0 and c >= +0 of :277-281, where both roots are <= 0) */
 void orc_world_hit_batch(const orc_world* w, const float* vec4, const float* f32, const int32_t* i32,
                          const float* rays, int64_t n, int32_t* hit_sphere, float* hit_t, uint8_t* disc_ge0, int nthreads);
 void orc_camera_derive(const orc_camera* cam, orc_camera_raw* out);

@@ -1,7 +1,8 @@
 """Direct test of the conservative sweep + walk: for batches of rays, the set of spheres that reach the
-render kernel's root tests must EQUAL {s : the reference's discriminant (shader.wgsl:274-282) is not < 0} -- "contains" is
-the conservativeness claim (no false negative at the sweep or at any level of the walk; a false negative on a sphere that
-is not the closest would be invisible in an image), "is contained in" holds because only members whose exact discriminant
+render kernel's root tests must CONTAIN every sphere whose discriminant (shader.wgsl:274-282) is not < 0 unless the sphere
+lies entirely behind the ray's origin (b >= 0 and c >= 0: both roots <= 0, never a hit) -- the conservativeness claim: no
+false negative at the sweep or at any level of the walk; a false negative on a sphere that is not the closest would be
+invisible in an image -- and must BE CONTAINED in {discriminant not < 0}, because only members whose exact discriminant
 is >= 0 are queued.  The winner (index, t) is compared with the oracle's world_hit as well.
 
 mrt_debug_world_hit runs the render kernel itself, instantiated to take its rays from an array, so sweep variant, hierarchy
@@ -72,7 +73,7 @@ def _rays_for(rng, sc, n_random, n_grazing, n_inside):
 
 def _check(mrt, O, sc, rays, sweep=0, hierarchy=None, what=""):
     packed = O.pack_world(to_oracle_spheres(O, sc))
-    ref_hit, ref_t, ref_set = O.world_hit_batch(packed, rays)
+    ref_hit, ref_t, ref_set, required = O.world_hit_batch(packed, rays)
     with mrt.State(mrt.Args(16, 16), seed=1) as st:
         if hierarchy is not None:
             st.debug_set_hierarchy(*hierarchy)
@@ -82,13 +83,14 @@ def _check(mrt, O, sc, rays, sweep=0, hierarchy=None, what=""):
         hit, t, cand = st.debug_world_hit(rays, len(sc))
     a2 = (rays[:, 3:].astype(np.float64) ** 2).sum(1)
     assert (np.abs(a2 - 1.0) < 5e-6).all()
-    missing = ref_set & ~cand
+    missing = required & ~cand
     extra = cand & ~ref_set
-    assert not missing.any(), (f"{what} (sweep variant {variant}): {int(missing.sum())} (ray, sphere) pairs with discriminant >= 0 never "
+    assert not missing.any(), (f"{what} (sweep variant {variant}): {int(missing.sum())} (ray, sphere) pairs with discriminant >= 0 and the sphere not behind the origin never "
                                f"reached the root tests; first ray {int(np.nonzero(missing.any(1))[0][0])}")
     assert not extra.any(), f"{what}: {int(extra.sum())} pairs reached the root tests with a negative discriminant"
     assert np.array_equal(hit, ref_hit), f"{what}: winners differ on {int((hit != ref_hit).sum())} rays"
     assert np.array_equal(t.view(np.uint32)[hit >= 0], ref_t.view(np.uint32)[hit >= 0]), f"{what}: t differs"
+    assert (required & ref_set).sum() == required.sum()
     return variant, int(ref_set.sum()), len(rays)
 
 
