@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--scene", default="cover-glass", choices=["cover-glass", "cover", "default", "stress"])
     ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"],
                     help="c3 (default): the headline 1920x1080x512 cover scene, weak-scaled with N; c4 / c5: BASELINE configs[3] / [4] as stated")
+    ap.add_argument("--rng", default="stream", choices=["stream", "counter"],
+                    help="stream (default): the reference's one Xoshiro128+ stream per pixel per frame; counter: per-sample hashed states, "
+                         "a pixel's samples summed in blocks of 64 that different lanes may render (extension, DESIGN.md 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     force_dist = os.environ.get("MRT_BENCH_FORCE_DIST") == "1"      # rehearses the RCCL path on one GPU
@@ -149,7 +152,7 @@ def main():
     if a.config in FIXED_CONFIGS:
         a.scene, width, height, spp = FIXED_CONFIGS[a.config]
         scaling = "strong"
-    headline = (not (a.width or a.height or a.spp) and a.depth == 50 and
+    headline = (not (a.width or a.height or a.spp) and a.depth == 50 and a.rng == "stream" and
                 ((a.config == "c3" and a.scene == "cover-glass" and a.gpus in WORKLOADS) or a.config in FIXED_CONFIGS))
     width, height, spp = a.width or width, a.height or height, a.spp or spp
     seed = 1
@@ -168,6 +171,8 @@ def main():
     st.set_world(spheres)
     if cam is not None:
         st.set_camera(cam)
+    if a.rng == "counter":
+        st.set_rng_mode(1)
     sweep_variant = st.debug_sweep_variant() or 1
     _, _, lrows, _ = st.shard_info()
     staging = torch.empty((world, lrows, width, 4), dtype=torch.float32, device=device) if (use_dist and rank == 0) else None
@@ -275,10 +280,12 @@ def main():
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed_max / max(1, a.steps) * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.config.upper() if headline else 'custom'}: {scene_names[a.scene]} ({n_spheres} spheres, scene_seed 1), "
+            "config": {"workload": f"{a.config.upper() if (headline or a.rng == 'counter') else 'custom'}: {scene_names[a.scene]} ({n_spheres} spheres, scene_seed 1), "
                                    f"{width}x{height}, {spp} spp per frame, depth {a.depth}, seed {seed}; "
                                    f"1 step = 1 redraw (+ RCCL gather to rank 0 when n_gpus > 1)",
-                       "headline": headline, "sharding": f"interleaved 8-row bands over {world} GPU(s)"},
+                       "headline": headline, "sharding": f"interleaved 8-row bands over {world} GPU(s)",
+                       "rng": {"stream": "one Xoshiro128+ stream per pixel per frame (the reference's, shader.wgsl:377-382)",
+                               "counter": "per-sample hashed states, blocks of 64 samples (extension)"}[a.rng]},
             "rccl_world_size": dist.get_world_size() if use_dist else 1,
             "ranks": rank_devices,
             "scene_upload_ms": st.last_set_world_ms(),
