@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     bool queue_empty = false;                   // wave-uniform: the global tile queue is exhausted
 
     // ---- per-lane task state
-    bool has_task = false, task_done = false, need_sample = false;
+    bool has_task = false, task_done = false;
     uint32_t s_done = 0, pix_trips = 0, texel = 0;
     float base_x = 0.0f, base_y = 0.0f;
     Rng rng; rng.draws = 0; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
@@ -421,94 +421,13 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
 #endif
 
     for (;;) {
-        // ---- release: the pixel's last sample is done -> leave its colour sum for finalize_kernel
-        const bool release = has_task && task_done;
-        if (release) {
-            if (!DBG) {
-                PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
-                const KArgPtr C = cold_args();
-                reinterpret_cast<PixAcc*>(C->pix_acc)[(CTR ? (size_t)(blk >> 7) * C->pix_stride : (size_t)0) + texel] = sa;
-            }
-            has_task = false;
-        }
-        // ---- refill: lanes would run dry -> take the next (heaviest remaining) tile of the frame
-        const unsigned long long need = __ballot(!has_task);
-        if (!queue_empty && avail < (uint32_t)__popcll(need)) {
-            const KArgPtr C = cold_args();
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(C->tile_queue, 1u);
-            t = __builtin_amdgcn_readfirstlane(t);
-            const uint32_t n_layers = (CTR && !PILOT) ? C->n_blocks : 1u;
-            if (t >= C->n_tiles * n_layers) {
-                queue_empty = true;
-            } else {
-                // layer by layer, each in the heaviest-first order of the tiles
-                const uint32_t lay = (CTR && !PILOT) ? t / C->n_tiles : 0u, ti = t - lay * C->n_tiles;
-                const uint32_t tile = lay * C->n_tiles + (C->tile_order ? C->tile_order[ti] : ti);
-                uint32_t fx, fy, ft, fl;
-                const uint32_t fq = (tile << 6) | lane;
-                const bool ok = locate(C, fq, fx, fy, ft, fl);
-                const unsigned long long m = __ballot(ok);
-                if (ok) ring[(tail + rank_in(m)) & (kRingCap - 1u)] = fq;
-                const uint32_t nf = (uint32_t)__popcll(m);
-                tail += nf;
-                avail += nf;
-            }
-        }
-        // ---- acquire: idle lanes take the pixels at the front of the FIFO
-        if (need != 0ull && avail != 0u) {
-            const uint32_t rk = rank_in(need);
-            const bool take = !has_task && rk < avail;
-            if (take) {
-                const KArgPtr C = cold_args();
-                uint32_t px, py, layer;
-                locate(C, ring[(head + rk) & (kRingCap - 1u)], px, py, texel, layer);
-                const float Wf = (float)C->locals.shape[0], Hf = (float)C->locals.shape[1];
-                base_x = (((float)px + 0.5f) - 0.5f * Wf) * pixel_side;            // fs_main :374
-                base_y = (((float)py + 0.5f) - 0.5f * Hf) * pixel_side;
-                const uint4 sd = reinterpret_cast<const uint4*>(C->seeds)[texel];     // xoshiro128plus_load :44-47
-                rng.s0 = sd.x ^ C->locals.rng_shuffle[0];
-                rng.s1 = sd.y ^ C->locals.rng_shuffle[1];
-                rng.s2 = sd.z ^ C->locals.rng_shuffle[2];
-                rng.s3 = sd.w ^ C->locals.rng_shuffle[3];
-                color = v3(0.0f, 0.0f, 0.0f);                                         // :376
-                s_done = 0;
-                pix_trips = 0;
-                has_task = true;
-                if (CTR) {      // this lane's block of the pixel's samples
-                    const uint32_t first = layer * kCtrBlock;
-                    const uint32_t cnt = spp > first ? (spp - first < kCtrBlock ? spp - first : kCtrBlock) : 0u;
-                    blk = (layer << 7) | cnt;
-                }
-                task_done = (spp == 0u);                // nothing to draw: colour 0/0, as the reference
-                need_sample = !task_done;
-                if (DBG) {
-                    const float* const r6 = C->dbg_rays + 6u * (size_t)texel;
-                    o = v3(r6[0], r6[1], r6[2]);
-                    d = v3(r6[3], r6[4], r6[5]);
-                    depth_left = 1u;
-                    task_done = false;
-                    need_sample = false;
-                }
-            }
-            const uint32_t np = (uint32_t)__popcll(need);
-            const uint32_t took = np < avail ? np : avail;
-            head += took;
-            avail -= took;
-        }
-        if (!__any(has_task)) {
-            if (queue_empty) break;
-            continue;                       // an all-invalid edge tile: pull the next one
-        }
-        trips++;
-        MRT_STAMP(5);
-
         const bool live = has_task && !task_done;
         // One trip of the sample loop head, shader.wgsl:378-381: seeds the path (o, pre-normalised direction nd).
-        // It runs at the TAIL of the iteration in which a lane's path ended (or in which the lane acquired its
-        // pixel: such a lane sits out that iteration's world_hit, once per pixel), so that the new camera ray and
-        // the scattered rays share one normalize (:354 / :381) and every lane enters the next world_hit with a
-        // ray.  Per lane the draw order is the reference's: jitter, lens, then the path's draws.
+        // It runs at the TAIL of the iteration, for lanes whose path has just ended and for lanes that have just taken a
+        // new pixel from the FIFO (a finished pixel is released and the next one acquired right before it), so that
+        // the new camera ray and the scattered rays share one normalize (:354 / :381) and every lane enters the next
+        // world_hit with a ray.  The wave's first iteration has nothing to trace and only acquires.  Per lane the draw
+        // order is the reference's: jitter, lens, then the path's draws.
         auto new_sample = [&](V3& nd) {
             if (CTR) {      // extension: this sample's state = hash(pixel frame state, sample index)
                 // (the pixel's frame state -- seed texel ^ shuffle, :44-47 -- is re-read per sample rather than held in
@@ -554,11 +473,11 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
             depth_left = C->locals.ray_depth;
         };
-        const bool fresh = live && need_sample;         // pixel acquired in this iteration: nothing to trace or shade yet
-        if (live && !fresh) pix_trips++;
+        trips++;
+        if (live) pix_trips++;
 
         // ------------------------------------------------------------ world_hit, shader.wgsl:314-329
-        const bool trace = live && !fresh && depth_left != 0u;              // lanes inside the loop of :339
+        const bool trace = live && depth_left != 0u;                        // lanes inside the loop of :339
         if (COUNT) bounces += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(trace));
         float t_sup = 1.0e4f;                                               // :340
         int32_t best = -1;
@@ -829,22 +748,18 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             }
         }
         MRT_STAMP(3);
-        if (DBG) {
-            if (live) {
-                P.dbg_hit[2u * texel] = best;
-                P.dbg_hit[2u * texel + 1u] = (int32_t)__float_as_uint(t_sup);
-                task_done = true;
-            }
-            continue;
+        if (DBG && live) {
+            P.dbg_hit[2u * texel] = best;
+            P.dbg_hit[2u * texel + 1u] = (int32_t)__float_as_uint(t_sup);
+            task_done = true;
         }
 
         bool start_sample = false;
-        if (live) {
+        V3 ndir = d;
+        if (!DBG && live) {
             bool path_done = false;
-            V3 contrib = v3(0.0f, 0.0f, 0.0f), ndir = d;
-            if (fresh) {
-                // handled below: the pixel's first sample
-            } else if (depth_left == 0u) {
+            V3 contrib = v3(0.0f, 0.0f, 0.0f);
+            if (depth_left == 0u) {
                 path_done = true;                                           // loop :339 not entered -> :357
             } else {
                 if (best < 0) {
@@ -925,20 +840,100 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 }
             }
 
-            MRT_STAMP(4);
-            start_sample = fresh;
             if (path_done) {
                 color = color + contrib;                                    // :381
                 s_done++;
                 if (s_done < (CTR ? (blk & 127u) : spp)) start_sample = true; else task_done = true;
             }
-            if (start_sample) {
-                new_sample(ndir);
-                need_sample = false;
+        }
+        MRT_STAMP(4);
+
+        // ---- release: the pixel's last sample is done -> leave its colour sum for finalize_kernel
+        const bool release = has_task && task_done;
+        if (release) {
+            if (!DBG) {
+                PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
+                const KArgPtr C = cold_args();
+                reinterpret_cast<PixAcc*>(C->pix_acc)[(CTR ? (size_t)(blk >> 7) * C->pix_stride : (size_t)0) + texel] = sa;
             }
-            // normalize() of the scattered direction (:354) and of the next sample's camera ray (:381), one code
+            has_task = false;
+        }
+        // ---- refill: lanes would run dry -> take the next (heaviest remaining) tile of the frame
+        const unsigned long long need = __ballot(!has_task);
+        if (!queue_empty && avail < (uint32_t)__popcll(need)) {
+            const KArgPtr C = cold_args();
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(C->tile_queue, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            const uint32_t n_layers = (CTR && !PILOT) ? C->n_blocks : 1u;
+            if (t >= C->n_tiles * n_layers) {
+                queue_empty = true;
+            } else {
+                // layer by layer, each in the heaviest-first order of the tiles
+                const uint32_t lay = (CTR && !PILOT) ? t / C->n_tiles : 0u, ti = t - lay * C->n_tiles;
+                const uint32_t tile = lay * C->n_tiles + (C->tile_order ? C->tile_order[ti] : ti);
+                uint32_t fx, fy, ft, fl;
+                const uint32_t fq = (tile << 6) | lane;
+                const bool ok = locate(C, fq, fx, fy, ft, fl);
+                const unsigned long long m = __ballot(ok);
+                if (ok) ring[(tail + rank_in(m)) & (kRingCap - 1u)] = fq;
+                const uint32_t nf = (uint32_t)__popcll(m);
+                tail += nf;
+                avail += nf;
+            }
+        }
+        // ---- acquire: idle lanes take the pixels at the front of the FIFO
+        if (need != 0ull && avail != 0u) {
+            const uint32_t rk = rank_in(need);
+            const bool take = !has_task && rk < avail;
+            if (take) {
+                const KArgPtr C = cold_args();
+                uint32_t px, py, layer;
+                locate(C, ring[(head + rk) & (kRingCap - 1u)], px, py, texel, layer);
+                const float Wf = (float)C->locals.shape[0], Hf = (float)C->locals.shape[1];
+                base_x = (((float)px + 0.5f) - 0.5f * Wf) * pixel_side;            // fs_main :374
+                base_y = (((float)py + 0.5f) - 0.5f * Hf) * pixel_side;
+                const uint4 sd = reinterpret_cast<const uint4*>(C->seeds)[texel];     // xoshiro128plus_load :44-47
+                rng.s0 = sd.x ^ C->locals.rng_shuffle[0];
+                rng.s1 = sd.y ^ C->locals.rng_shuffle[1];
+                rng.s2 = sd.z ^ C->locals.rng_shuffle[2];
+                rng.s3 = sd.w ^ C->locals.rng_shuffle[3];
+                color = v3(0.0f, 0.0f, 0.0f);                                         // :376
+                s_done = 0;
+                pix_trips = 0;
+                has_task = true;
+                if (CTR) {      // this lane's block of the pixel's samples
+                    const uint32_t first = layer * kCtrBlock;
+                    const uint32_t cnt = spp > first ? (spp - first < kCtrBlock ? spp - first : kCtrBlock) : 0u;
+                    blk = (layer << 7) | cnt;
+                }
+                task_done = (spp == 0u);                // nothing to draw: colour 0/0, as the reference
+                start_sample = !task_done;
+                if (DBG) {
+                    const float* const r6 = C->dbg_rays + 6u * (size_t)texel;
+                    o = v3(r6[0], r6[1], r6[2]);
+                    d = v3(r6[3], r6[4], r6[5]);
+                    depth_left = 1u;
+                    task_done = false;
+                    start_sample = false;
+                }
+            }
+            const uint32_t np = (uint32_t)__popcll(need);
+            const uint32_t took = np < avail ? np : avail;
+            head += took;
+            avail -= took;
+        }
+        if (!__any(has_task)) {
+            if (queue_empty) break;
+            continue;                       // nothing acquired (an all-invalid edge tile): pull the next one
+        }
+        MRT_STAMP(5);
+
+        if (!DBG) {
+            if (start_sample) new_sample(ndir);
+            // normalize() of the scattered direction (:354) and of the new sample's camera ray (:381), one code
             // path for the lanes of either kind
-            if (!task_done) d = normalize3(ndir);
+            if (has_task && !task_done) d = normalize3(ndir);
         }
         MRT_STAMP(0);
         if (COUNT) started += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(start_sample));

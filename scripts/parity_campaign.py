@@ -51,6 +51,9 @@ def main():
                            float(rng.choice([0.0, 0.0, 0.5, 3.0])), float(rng.uniform(0.5, 12) * scale))
         w, h = int(rng.integers(8, 80)), int(rng.integers(8, 48))
         spp, depth = int(rng.choice([1, 2, 3, 5])), int(rng.choice([1, 2, 5, 13, 50]))
+        mode = int(rng.random() < 0.3)                      # counter-RNG mode, sometimes with several blocks of 64 samples
+        if mode and rng.random() < 0.4:
+            spp, w, h = int(rng.choice([64, 65, 130, 200])), min(w, 24), min(h, 16)
         seed = int(rng.integers(0, 2 ** 62))
         hier = (int(rng.integers(1, 5)), int(rng.choice([1, 4, 16, 64, 256])))
         lim = max(float(np.abs(sc["center"]).max()), float(np.abs(sc["radius"]).max()))
@@ -58,19 +61,20 @@ def main():
             skipped += 1
             continue
         cnt = O.Counters()
-        ref = oracle_render(O, sc, cam, w, h, spp, depth, seed, 1, 1.0, counters=cnt)
+        ref = oracle_render(O, sc, cam, w, h, spp, depth, seed, 1, 1.0, counters=cnt, rng_mode=mode)
         with M.State(M.Args(w, h, spp, depth, 1.0), seed=seed) as st:
             st.debug_set_hierarchy(*hier)
             st.debug_set_sweep(int(rng.integers(0, 3)))      # automatic / VALU / matrix-core sweep
             st.set_world(sc)
             if cam is not None: st.set_camera(cam)
+            st.set_rng_mode(mode)
             st.render(1)
             got, c = st.read_framebuffer(), st.read_counters()
         same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
         ok = same.all() and c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
         if not ok:
             fails += 1
-            print(f"FAIL case {case}: n={n} {w}x{h}x{spp} depth {depth} hier {hier} scale {scale:.3g}: {mismatch_report(got, ref)}", flush=True)
+            print(f"FAIL case {case}: n={n} {w}x{h}x{spp} depth {depth} rng_mode {mode} hier {hier} scale {scale:.3g}: {mismatch_report(got, ref)}", flush=True)
         if (case - first) % 25 == 24:
             print(f"... {case - first + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
     print(f"campaign: {n_cases} cases ({skipped} skipped: out of the ABI's coordinate range), {fails} failures")
