@@ -307,7 +307,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }   // compiler-level only: LDS runs a wave's accesses in order
-
 // lanes below `lane` whose bit is set in the 64-bit ballot `mask`
 __device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
