@@ -352,7 +352,8 @@ int mrt_scene_load(const char* path, mrt_sphere* out, size_t cap, mrt_camera* ca
  * rows flipped to top-down (sample_framebuffer.wgsl:24). */
 int mrt_write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height);
 int mrt_write_ppm(const char* path, const float* rgba, uint32_t width, uint32_t height);
-uint8_t mrt_srgb8(float linear);      /* the per-channel conversion mrt_write_ppm applies */
+int mrt_write_png(const char* path, const float* rgba, uint32_t width, uint32_t height);   /* 8-bit RGB, same encoding as the PPM, + sRGB chunk */
+uint8_t mrt_srgb8(float linear);      /* the per-channel conversion mrt_write_ppm / mrt_write_png apply */
 
 #ifdef __cplusplus
 }

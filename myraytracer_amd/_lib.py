@@ -22,7 +22,7 @@ EXPORTS = [
     "mrt_kernel_ms_history", "mrt_debug_read_counters", "mrt_debug_wave_log", "mrt_debug_set_tile_sort", "mrt_debug_set_cluster_factor", "mrt_debug_set_hierarchy", "mrt_debug_set_sweep", "mrt_debug_sweep_variant", "mrt_debug_build_hierarchy", "mrt_debug_read_pixel_costs", "mrt_debug_set_schedule",
     "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_scene_default", "mrt_scene_cover",
     "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
-    "mrt_srgb8", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
+    "mrt_srgb8", "mrt_write_png", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
     "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit",
 ]
 
@@ -152,6 +152,7 @@ def load():
         "mrt_write_pfm": (i32, [C.c_char_p, vp, u32, u32]),
         "mrt_write_ppm": (i32, [C.c_char_p, vp, u32, u32]),
         "mrt_srgb8": (C.c_uint8, [f32]),
+        "mrt_write_png": (i32, [C.c_char_p, vp, u32, u32]),
         "mrt_gather": (i32, [P(vp), u32, u32]),
         "mrt_gather_rccl": (i32, [vp, vp, u32]),
         "mrt_gathered_device_ptr": (vp, [vp]),

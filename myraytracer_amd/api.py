@@ -209,10 +209,11 @@ def load_scene(path: str):
 
 
 def write_image(path: str, rgba: np.ndarray):
-    """rgba: (H, W, 4) f32, row 0 = bottom.  .ppm -> 8-bit sRGB (what the reference's surface shows), anything else -> PFM."""
+    """rgba: (H, W, 4) f32, row 0 = bottom.  .ppm / .png -> 8-bit sRGB (what the reference's surface shows), anything else -> PFM."""
     rgba = np.ascontiguousarray(rgba, np.float32)
     h, w, _ = rgba.shape
-    fn = _lib.load().mrt_write_ppm if path.endswith(".ppm") else _lib.load().mrt_write_pfm
+    L = _lib.load()
+    fn = L.mrt_write_ppm if path.endswith(".ppm") else L.mrt_write_png if path.endswith(".png") else L.mrt_write_pfm
     st = fn(path.encode(), rgba.ctypes.data, w, h)
     if st:
         raise MrtError(st, "write_image", path)

@@ -21,7 +21,7 @@ static void usage() {
         "usage: native_runner [--width N] [--height N] [--samples-per-frame N] [--ray-depth N]\n"
         "                     [--max-framebuffer-weight F] [--frames N] [--seed N]\n"
         "                     [--scene default|cover|cover-glass|stress | --scene-file FILE] [--save-scene FILE]\n"
-        "                     [--out FILE.pfm|FILE.ppm] [--device N | --gpus N | --devices a,b,...]\n");
+        "                     [--out FILE.pfm|FILE.ppm|FILE.png] [--device N | --gpus N | --devices a,b,...]\n");
 }
 
 int main(int argc, char** argv) {
@@ -111,9 +111,10 @@ int main(int argc, char** argv) {
         std::vector<float> fb((size_t)args.width * args.height * 4);
         if (n_gpus > 1) TRY(ctxs[0], mrt_read_gathered(ctxs[0], fb.data(), fb.size()));
         else TRY(ctxs[0], mrt_read_framebuffer(ctxs[0], fb.data(), fb.size()));
-        const bool ppm = out.size() > 4 && out.substr(out.size() - 4) == ".ppm";
-        int s2 = ppm ? mrt_write_ppm(out.c_str(), fb.data(), args.width, args.height)
-                     : mrt_write_pfm(out.c_str(), fb.data(), args.width, args.height);
+        const std::string ext = out.size() > 4 ? out.substr(out.size() - 4) : "";
+        int s2 = ext == ".ppm" ? mrt_write_ppm(out.c_str(), fb.data(), args.width, args.height)
+               : ext == ".png" ? mrt_write_png(out.c_str(), fb.data(), args.width, args.height)
+                               : mrt_write_pfm(out.c_str(), fb.data(), args.width, args.height);
         if (s2 != MRT_OK) { std::fprintf(stderr, "cannot write %s\n", out.c_str()); destroy_all(); return 1; }
         std::printf("wrote %s\n", out.c_str());
     }

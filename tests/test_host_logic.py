@@ -111,6 +111,41 @@ def test_image_writers(mrt, tmp_path):
     assert body[2, 0, 0] == 255 and body[0, 0, 2] == 137 and body[1].sum() == 0     # flipped, sRGB OETF
 
 
+def test_png_writer_round_trips_through_zlib(mrt, tmp_path):
+    """mrt_write_png: a valid PNG (signature, IHDR, sRGB, IDAT of stored deflate blocks, IEND, every CRC) whose pixels are the
+    PPM's, for an image large enough to need several 64 KB blocks."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(1)
+    h, w = 150, 200                                  # 90 KB of scanlines -> two stored blocks
+    img = rng.random((h, w, 4), dtype=np.float32) * 1.2 - 0.1
+    p = str(tmp_path / "a.png")
+    mrt.write_image(p, img)
+    raw = open(p, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, ty = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(ty + data) & 0xFFFFFFFF, ty
+        chunks.append((ty, data))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"sRGB", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+    scan = np.frombuffer(zlib.decompress(chunks[2][1]), np.uint8).reshape(h, 1 + 3 * w)
+    assert (scan[:, 0] == 0).all()
+    pix = scan[:, 1:].reshape(h, w, 3)
+    L = mrt._lib.load()
+    want = np.array([[[L.mrt_srgb8(float(v)) for v in px[:3]] for px in row] for row in img[::-1][:3]], np.uint8)
+    assert np.array_equal(pix[:3], want)             # top row of the file = last framebuffer row
+    q = str(tmp_path / "a.ppm")
+    mrt.write_image(q, img)
+    ppm = open(q, "rb").read()
+    body = np.frombuffer(ppm[len(f"P6\n{w} {h}\n255\n"):], np.uint8).reshape(h, w, 3)
+    assert np.array_equal(body, pix)
+
+
 def test_ppm_is_the_srgb_surface_encoding(mrt):
     """lib.rs:349-351 / :1133: the present pass stores linear values to the adapter's sRGB surface, i.e. the
     piecewise sRGB OETF rounded to 8 bits -- not a gamma-2 square root."""
