@@ -117,11 +117,14 @@ def main():
     ap.add_argument("--scene", default="cover-glass", choices=["cover-glass", "cover", "default", "stress"])
     ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"],
                     help="c3 (default): the headline 1920x1080x512 cover scene, weak-scaled with N; c4 / c5: BASELINE configs[3] / [4] as stated")
-    ap.add_argument("--rng", default="stream", choices=["stream", "counter"],
-                    help="stream (default): the reference's one Xoshiro128+ stream per pixel per frame; counter: per-sample hashed states, "
-                         "a pixel's samples summed in blocks of 64 that different lanes may render (extension, DESIGN.md 4)")
+    ap.add_argument("--rng", default=None, choices=["stream", "counter"],
+                    help="stream (default for c3 / c4): the reference's one Xoshiro128+ stream per pixel per frame; counter (default for c5, "
+                         "whose 8-GPU shares are pixel-starved in the stream mode): per-sample hashed states, a pixel's samples summed in "
+                         "blocks of 64 that different lanes may render (north_star's counter-based RNG; extension, DESIGN.md 4 / 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+    if a.rng is None:
+        a.rng = "counter" if a.config == "c5" else "stream"
     force_dist = os.environ.get("MRT_BENCH_FORCE_DIST") == "1"      # rehearses the RCCL path on one GPU
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or force_dist):
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
@@ -152,7 +155,7 @@ def main():
     if a.config in FIXED_CONFIGS:
         a.scene, width, height, spp = FIXED_CONFIGS[a.config]
         scaling = "strong"
-    headline = (not (a.width or a.height or a.spp) and a.depth == 50 and a.rng == "stream" and
+    headline = (not (a.width or a.height or a.spp) and a.depth == 50 and a.rng == ("counter" if a.config == "c5" else "stream") and
                 ((a.config == "c3" and a.scene == "cover-glass" and a.gpus in WORKLOADS) or a.config in FIXED_CONFIGS))
     width, height, spp = a.width or width, a.height or height, a.spp or spp
     seed = 1
