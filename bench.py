@@ -122,6 +122,9 @@ def main():
                          "whose 8-GPU shares are pixel-starved in the stream mode): per-sample hashed states, a pixel's samples summed in "
                          "blocks of 64 that different lanes may render (north_star's counter-based RNG; extension, DESIGN.md 4 / 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: after the timed run rank 0 renders the unsharded frame itself and requires the gathered image of the "
+                         "last step to be bit-identical (costs one full frame on rank 0; not part of any timing)")
     a = ap.parse_args()
     if a.rng is None:
         a.rng = "counter" if a.config == "c5" else "stream"
@@ -144,11 +147,18 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MRT_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, the gather goes
+    # through host memory): it exercises launch, sharding, gather and --verify end to end; its timing means nothing
+    backend = os.environ.get("MRT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_dist = world > 1 or force_dist
     if use_dist:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     width, height, spp = WORKLOADS.get(a.gpus, WORKLOADS[1])
     scaling = "weak"
@@ -169,7 +179,7 @@ def main():
         spheres, cam = M.scene_default(), None
 
     stream = torch.cuda.current_stream(device)
-    st = M.State(M.Args(width, height, spp, a.depth, 1.0), seed=seed, device=local_rank,
+    st = M.State(M.Args(width, height, spp, a.depth, 1.0), seed=seed, device=dev_index,
                  shard=(rank, world) if world > 1 else None, stream=stream.cuda_stream)
     st.set_world(spheres)
     if cam is not None:
@@ -178,12 +188,17 @@ def main():
         st.set_rng_mode(1)
     sweep_variant = st.debug_sweep_variant() or 1
     _, _, lrows, _ = st.shard_info()
-    staging = torch.empty((world, lrows, width, 4), dtype=torch.float32, device=device) if (use_dist and rank == 0) else None
+    gather_device = device if backend == "nccl" else torch.device("cpu")
+    staging = torch.empty((world, lrows, width, 4), dtype=torch.float32, device=gather_device) if (use_dist and rank == 0) else None
 
     def step():
         st.redraw()                                    # async on torch's current stream
         if use_dist:
-            return mdist.gather_framebuffer(mdist.framebuffer_tensor(st, device), height, 0, staging)
+            local = mdist.framebuffer_tensor(st, device)
+            if backend != "nccl":
+                torch.cuda.synchronize(device)
+                local = local.cpu()
+            return mdist.gather_framebuffer(local, height, 0, staging)
         return None
 
     def fence():
@@ -215,8 +230,9 @@ def main():
     c0 = st.read_counters()
     fence()
     t0 = time.perf_counter()
+    last_image = None
     for _ in range(a.steps):
-        step()
+        last_image = step()
     fence()
     elapsed = time.perf_counter() - t0
     c1 = st.read_counters()
@@ -233,15 +249,32 @@ def main():
         elapsed_render_only = time.perf_counter() - t0
 
     # whole-job numbers: max time over ranks, summed counters
-    stats = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms)), elapsed_render_only or 0.0], dtype=torch.float64, device=device)
+    stats = torch.tensor([elapsed, sum(kernel_ms) / max(1, len(kernel_ms)), elapsed_render_only or 0.0], dtype=torch.float64, device=gather_device)
     sums = torch.tensor([c1["world_hit_calls"] - c0["world_hit_calls"], c1["samples"] - c0["samples"],
                          c1["lane_slots"] - c0["lane_slots"], c1["member_tests"] - c0["member_tests"]],
-                        dtype=torch.float64, device=device)
+                        dtype=torch.float64, device=gather_device)
     if use_dist:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     elapsed_max, kernel_ms_max, render_only_max = float(stats[0]), float(stats[1]), float(stats[2])
     hits, samples_counted, lane_slots, member_tests = (float(x) for x in sums)
+
+    # --verify: the image the ranks assembled == the frame one context renders alone (same seed, same number of redraws)
+    gather_verified = None
+    if a.verify and use_dist:
+        if rank == 0 and last_image is not None:
+            want_frames = (a.warmup + a.steps)
+            with M.State(M.Args(width, height, spp, a.depth, 1.0), seed=seed, device=dev_index) as solo:
+                solo.set_world(spheres)
+                if cam is not None:
+                    solo.set_camera(cam)
+                if a.rng == "counter":
+                    solo.set_rng_mode(1)
+                solo.render(want_frames)
+                solo.sync()
+                ref = torch.from_numpy(solo.read_framebuffer())
+            gather_verified = bool(torch.equal(last_image.cpu().view(torch.int32), ref.view(torch.int32)))
+            assert gather_verified, "the gathered image differs from the unsharded frame"
 
     # which ranks RCCL actually connected: every rank reports its device; the root checks the communicator's size
     rank_devices = [None] * world
@@ -289,7 +322,7 @@ def main():
                        "headline": headline, "sharding": f"interleaved 8-row bands over {world} GPU(s)",
                        "rng": {"stream": "one Xoshiro128+ stream per pixel per frame (the reference's, shader.wgsl:377-382)",
                                "counter": "per-sample hashed states, blocks of 64 samples (extension)"}[a.rng]},
-            "rccl_world_size": dist.get_world_size() if use_dist else 1,
+            "rccl_world_size": dist.get_world_size() if use_dist else 1, "backend": backend if use_dist else None,
             "ranks": rank_devices,
             "scene_upload_ms": st.last_set_world_ms(),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -325,6 +358,10 @@ def main():
         }
         if first_frame_check is not None:
             out["first_frame_counters_equal_oracle"] = first_frame_check
+        if gather_verified is not None:
+            out["gathered_image_equals_unsharded_frame"] = gather_verified
+        if use_dist and backend != "nccl":
+            out["rehearsal"] = f"backend {backend}: ranks share GPUs and gather through host memory -- a functional rehearsal, not a measurement"
         if use_dist and render_only_max > 0:
             out["render_only_value"] = total_samples / render_only_max * 1e-6
             out["render_only_ms_per_step"] = render_only_max / max(1, a.steps) * 1e3

@@ -193,7 +193,9 @@ int mrt_read_seeds(mrt_ctx* ctx, uint32_t* out, size_t cap_u32);    /* this shar
  * sample_count += 1, framebuffer_weight = min(max_w, n/(n+1)), new rng_shuffle, Locals
  * update.  Asynchronous on the ctx's stream. */
 int mrt_redraw(mrt_ctx* ctx);
-/* `frames` x mrt_redraw */
+/* `frames` x mrt_redraw: the same images.  Frames are independent until their blend, so when the (shard of the) image has
+ * fewer than about two pixels per GPU lane -- a pixel is one sequential chain of samples, lib.rs:299-306's remedy for that is
+ * more frames -- up to 8 consecutive frames of the stream mode share one render launch. */
 int mrt_render(mrt_ctx* ctx, uint32_t frames);
 int mrt_sync(mrt_ctx* ctx);
 /* Restart accumulation: zero framebuffers, frame counter 0, weight 0, shuffle [0;4]. */
@@ -292,6 +294,8 @@ int mrt_debug_world_hit(mrt_ctx* ctx, const float* rays, size_t n, int32_t* hit_
                         size_t cand_words_per_ray);
 /* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
 int mrt_debug_sweep_variant(mrt_ctx* ctx);
+/* Diagnostic A/B switch: 0 makes mrt_render launch every frame on its own. */
+int mrt_debug_set_frame_batching(mrt_ctx* ctx, int enabled);
 /* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */
 int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);
 /* Diagnostic / tuning: pilot samples per pixel, waves per CU (0 = automatic).  Before the first

@@ -23,7 +23,7 @@ EXPORTS = [
     "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_scene_default", "mrt_scene_cover",
     "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
     "mrt_srgb8", "mrt_write_png", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
-    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit",
+    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit", "mrt_debug_set_frame_batching",
 ]
 
 
@@ -162,6 +162,7 @@ def load():
         "mrt_unshard_rows": (i32, [vp, u32, u32, u32, vp]),
         "mrt_debug_last_set_world_ms": (i32, [vp, P(f32)]),
         "mrt_debug_world_hit": (i32, [vp, vp, sz, vp, vp, sz]),
+        "mrt_debug_set_frame_batching": (i32, [vp, i32]),
     }
     assert sorted(sig) == sorted(EXPORTS)
     for name, (res, args) in sig.items():

@@ -392,6 +392,10 @@ class State:
         bits = np.unpackbits(cand.view(np.uint8), axis=1, bitorder="little")[:, :n_spheres].astype(bool)
         return hit[:, 0].copy(), hit[:, 1].copy().view(np.float32), bits
 
+    def debug_set_frame_batching(self, enabled: bool):
+        """A/B switch: False makes render(frames) launch every frame on its own."""
+        self._check(self._L.mrt_debug_set_frame_batching(self._ctx, int(enabled)), "mrt_debug_set_frame_batching")
+
     def last_set_world_ms(self) -> float:
         """Host wall time of the last scene upload (hierarchy build + copies); one-off per scene."""
         ms = C.c_float()

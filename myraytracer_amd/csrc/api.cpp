@@ -68,7 +68,7 @@ void free_frame_buffers(mrt_ctx* c) {
         if (S.d_pix_acc) (void)hipFree(S.d_pix_acc);
         S.d_tile_cost = S.d_tile_order = S.d_sort_scratch = nullptr;
         S.d_pix_acc = nullptr;
-        S.pix_acc_layers = 0; S.blocks = 1;
+        S.pix_acc_layers = 0; S.cost_first_layer = 0; S.cost_layers = 1;
         S.cost_valid = false;
     }
     c->d_seeds = nullptr; c->d_fb[0] = c->d_fb[1] = nullptr;
@@ -107,7 +107,7 @@ int alloc_frame_buffers(mrt_ctx* c) {
         HIP_TRY(c, hipMalloc(&S.d_sort_scratch, (1024 + 16) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&S.d_pix_acc, (n ? n : 1) * 16));
         HIP_TRY(c, hipMemsetAsync(S.d_pix_acc, 0, (n ? n : 1) * 16, c->stream));
-        S.pix_acc_layers = 1; S.blocks = 1;
+        S.pix_acc_layers = 1; S.cost_first_layer = 0; S.cost_layers = 1;
         S.cost_valid = false;
     }
     c->inputs_dirty = true;
@@ -953,18 +953,19 @@ extern "C" {
 
 // State::redraw, lib.rs:241-307 (raytrace pass + swap + weight/shuffle update; the present
 // pass needs a window surface and is out of scope)
-int mrt_redraw(mrt_ctx* c) {
-    if (!c) return MRT_ERR_INVALID_ARG;
+// `batch` >= 1 consecutive frames with ONE render launch (batch > 1: stream mode only, see mrt_render): the raytrace pass
+// of State::redraw for each of them, then per frame -- in order -- the blend, the swap and the weight / shuffle update.
+static int redraw_frames(mrt_ctx* c, uint32_t batch) {
     if (!c->have_world) return fail(c, MRT_ERR_NO_SCENE, "mrt_redraw: no scene (call mrt_set_world first)");
     HIP_TRY(c, hipSetDevice(c->device));
+    const bool counter = c->locals.rng_mode == MRT_RNG_COUNTER;
+    if (batch < 1 || batch > mrt::kMaxFrameBatch || (counter && batch != 1)) return fail(c, MRT_ERR_INVALID_ARG, "redraw_frames: batch %u", batch);
     mrt::KParams p;
     std::memset(&p, 0, sizeof p);
     p.locals = c->locals;
     fill_scene_params(c, p);
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.seeds = c->d_seeds;
-    p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
-    p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
     p.counters = c->d_counters;
     p.wave_log = c->d_wave_log;
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
@@ -973,26 +974,34 @@ int mrt_redraw(mrt_ctx* c) {
     p.tile_queue = S.d_sort_scratch + 1024;
     p.tile_order = nullptr;
     p.tile_cost = S.d_tile_cost;
-    // counter-RNG mode: one layer of colour sums per block of MRT_COUNTER_BLOCK samples; the slot's buffer grows
-    // on demand (a frame of this slot that is still in flight is waited for first)
+    // Layers of colour sums.  Counter-RNG mode: one per block of MRT_COUNTER_BLOCK samples of the frame.  Stream
+    // mode: one per frame of the batch, each with the rng_shuffle the frame would have had on its own (lib.rs:305's stand-in).
+    // The slot's buffer grows on demand (a frame of this slot that is still in flight is waited for first).
+    const size_t n = local_texels(c) ? local_texels(c) : 1;
     {
         const uint32_t spp = c->locals.samples_per_frame;
-        uint32_t blocks = 1;
-        if (c->locals.rng_mode == MRT_RNG_COUNTER && spp > MRT_COUNTER_BLOCK) blocks = (spp + MRT_COUNTER_BLOCK - 1) / MRT_COUNTER_BLOCK;
-        const size_t n = local_texels(c) ? local_texels(c) : 1;
-        if ((uint64_t)blocks * n >= (1ull << 32) || (uint64_t)blocks * c->n_tiles >= (1ull << 26))
-            return fail(c, MRT_ERR_INVALID_ARG, "mrt_redraw: %u spp in counter mode over %zu pixels exceeds the tile queue's range", spp, n);
-        if (S.pix_acc_layers < blocks) {
+        uint32_t layers = batch;
+        if (counter && spp > MRT_COUNTER_BLOCK) layers = (spp + MRT_COUNTER_BLOCK - 1) / MRT_COUNTER_BLOCK;
+        if ((uint64_t)layers * n >= (1ull << 32) || (uint64_t)layers * c->n_tiles >= (1ull << 26))
+            return fail(c, MRT_ERR_INVALID_ARG, "mrt_redraw: %u layers of colour sums over %zu pixels exceed the tile queue's range", layers, n);
+        if (S.pix_acc_layers < layers) {
             HIP_TRY(c, hipStreamSynchronize(S.stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (S.d_pix_acc) (void)hipFree(S.d_pix_acc);
             S.d_pix_acc = nullptr; S.pix_acc_layers = 0;
-            HIP_TRY(c, hipMalloc(&S.d_pix_acc, (size_t)blocks * n * 16));
-            S.pix_acc_layers = blocks;
+            HIP_TRY(c, hipMalloc(&S.d_pix_acc, (size_t)layers * n * 16));
+            S.pix_acc_layers = layers;
         }
-        S.blocks = blocks;
-        p.n_blocks = blocks;
+        // what mrt_debug_read_pixel_costs reads back: a counter-mode frame's cost is the sum over its blocks, a batch's last
+        // frame is its last layer
+        S.cost_first_layer = counter ? 0u : batch - 1u;
+        S.cost_layers = counter ? layers : 1u;
+        p.n_blocks = layers;
         p.pix_stride = (uint32_t)n;
+        for (uint32_t b = 0; b < batch; b++) {
+            if (b == 0) std::memcpy(p.layer_shuffle[0], c->locals.rng_shuffle, 16);
+            else mrt_frame_shuffle(c->seed, c->frames_done == UINT32_MAX ? UINT32_MAX : c->frames_done + b, p.layer_shuffle[b]);
+        }
     }
     p.pix_acc = S.d_pix_acc;
     // side stream: wait for the scene / seeds uploads and for this slot's previous frame (n-2) to
@@ -1025,26 +1034,56 @@ int mrt_redraw(mrt_ctx* c) {
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], S.stream));
     HIP_TRY(c, hipEventRecord(S.render_done, S.stream));
     c->timed_frames++;
-    // caller's stream: blend into the accumulated framebuffer (shader.wgsl:383-385) once the render is done
+    // caller's stream: blend into the accumulated framebuffer (shader.wgsl:383-385) once the render is done -- frame by frame
     HIP_TRY(c, hipStreamWaitEvent(c->stream, S.render_done, 0));
-    int fe = mrt::launch_finalize(p, c->stream);
-    if (fe) return fail(c, MRT_ERR_HIP, "finalize launch failed: %s", hipGetErrorString((hipError_t)fe));
+    for (uint32_t b = 0; b < batch; b++) {
+        p.out = c->d_fb[c->target];              // framebuffers.target  (lib.rs:250)
+        p.prev = c->d_fb[c->target ^ 1];         // framebuffers.secondary (lib.rs:265)
+        p.locals.framebuffer_weight = c->locals.framebuffer_weight;
+        if (!counter) { p.pix_acc = (char*)S.d_pix_acc + (size_t)b * n * 16; p.n_blocks = 1; }
+        int fe = mrt::launch_finalize(p, c->stream);
+        if (fe) return fail(c, MRT_ERR_HIP, "finalize launch failed: %s", hipGetErrorString((hipError_t)fe));
+        c->target ^= 1;                                                       // framebuffers.swap(), lib.rs:299
+        if (c->frames_done != UINT32_MAX) c->frames_done++;                   // saturating_add, lib.rs:300
+        c->locals.framebuffer_weight = mrt_frame_weight(c->frames_done, c->args.max_framebuffer_weight);  // :301-304
+        mrt_frame_shuffle(c->seed, c->frames_done, c->locals.rng_shuffle);    // :305 (deterministic stand-in)
+    }
     HIP_TRY(c, hipEventRecord(S.finalize_done, c->stream));
     S.cost_valid = true;
     c->frame_seq++;
-
-    c->target ^= 1;                                                       // framebuffers.swap(), lib.rs:299
-    if (c->frames_done != UINT32_MAX) c->frames_done++;                   // saturating_add, lib.rs:300
-    c->locals.framebuffer_weight = mrt_frame_weight(c->frames_done, c->args.max_framebuffer_weight);  // :301-304
-    mrt_frame_shuffle(c->seed, c->frames_done, c->locals.rng_shuffle);    // :305 (deterministic stand-in)
+    c->shuffle_overridden = false;
     return MRT_OK;
 }
 
+int mrt_redraw(mrt_ctx* c) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    return redraw_frames(c, 1);
+}
+
+// `frames` x State::redraw.  Frames are independent until their blend (each has its own rng_shuffle and its own colour
+// sums), so when the shard has too few pixels to fill the GPU -- a pixel is one sequential chain of samples -- one launch
+// renders up to kMaxFrameBatch consecutive frames: a lane that finishes a pixel of frame f takes one of frame f+1.  Every
+// frame's image is the one mrt_redraw would have produced.
 int mrt_render(mrt_ctx* c, uint32_t frames) {
-    for (uint32_t i = 0; i < frames; i++) {
-        int st = mrt_redraw(c);
+    if (!c) return MRT_ERR_INVALID_ARG;
+    while (frames != 0) {
+        uint32_t batch = 1;
+        const bool starved = c->n_tiles < 2u * c->n_waves;                 // fewer than two pixels per lane
+        if (c->batch_frames && starved && frames >= 2 && c->locals.rng_mode == MRT_RNG_PIXEL_STREAM && !c->shuffle_overridden &&
+            c->n_tiles != 0) {
+            const uint32_t want = (6u * c->n_waves + c->n_tiles - 1u) / c->n_tiles;   // about six pixels per lane (chains differ 10 x in length)
+            batch = std::min(std::min(frames, (uint32_t)mrt::kMaxFrameBatch), std::max(want, 1u));
+        }
+        int st = redraw_frames(c, batch);
         if (st != MRT_OK) return st;
+        frames -= batch;
     }
+    return MRT_OK;
+}
+
+int mrt_debug_set_frame_batching(mrt_ctx* c, int enabled) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    c->batch_frames = enabled != 0;
     return MRT_OK;
 }
 
@@ -1057,10 +1096,10 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
     HIP_TRY(c, sync_all(c));
     const mrt_ctx::FrameSlot& S = c->slot[(c->frame_seq + mrt_ctx::kFrameSlots - 1u) % mrt_ctx::kFrameSlots];
     std::vector<uint32_t> tmp(n * 4), layer(n * 4);
-    HIP_TRY(c, hipMemcpyAsync(tmp.data(), S.d_pix_acc, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), (const char*)S.d_pix_acc + (size_t)S.cost_first_layer * n * 16, n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (uint32_t b = 1; b < S.blocks; b++) {       // counter mode: a pixel's cost is the sum over its blocks
-        HIP_TRY(c, hipMemcpyAsync(layer.data(), (const char*)S.d_pix_acc + (size_t)b * n * 16, n * 16, hipMemcpyDeviceToHost, c->stream));
+    for (uint32_t b = 1; b < S.cost_layers; b++) {       // counter mode: a pixel's cost is the sum over its blocks
+        HIP_TRY(c, hipMemcpyAsync(layer.data(), (const char*)S.d_pix_acc + (size_t)(S.cost_first_layer + b) * n * 16, n * 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (size_t i = 0; i < n; i++) tmp[4 * i + 3] += layer[4 * i + 3];
     }
@@ -1147,6 +1186,7 @@ int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_ou
     p.shard_rank = 0; p.shard_world = 1;
     p.tiles_x = 1; p.n_tiles = (uint32_t)(n_pad / 64);
     p.tile_queue = d_queue;
+    p.n_blocks = 1; p.pix_stride = 0;
     p.dbg_rays = d_rays; p.dbg_hit = d_hit; p.dbg_cand = d_cand; p.dbg_words = (uint32_t)words;
     int le = mrt::launch_debug_world_hit(p, c->n_waves, c->stream);
     if (le == 0) e = hipStreamSynchronize(c->stream);
@@ -1233,6 +1273,7 @@ int mrt_get_locals(mrt_ctx* c, mrt_locals* out) {
 int mrt_set_rng_shuffle(mrt_ctx* c, const uint32_t s[4]) {
     if (!c || !s) return MRT_ERR_INVALID_ARG;
     std::memcpy(c->locals.rng_shuffle, s, 16);
+    c->shuffle_overridden = true;          // the next frame is rendered on its own (mrt_render does not batch it)
     return MRT_OK;
 }
 

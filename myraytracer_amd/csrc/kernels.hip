@@ -381,14 +381,16 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     const SphQuadPtr sph_quads = (SphQuadPtr)(uintptr_t)P.clusters;
     const float pixel_side = 2.0f / (float)H;                 // fs_main :373
 
-    // pixel id q = (virtual tile << 6) | lane-in-tile -> coordinates.  In the counter-RNG mode a frame is n_blocks LAYERS
-    // of the image (layer b = samples [64 b, 64 b + 64) of every pixel, summed separately: the samples of a pixel are
-    // independent there), and virtual tile = layer * n_tiles + tile; otherwise there is one layer.
+    // pixel id q = (virtual tile << 6) | lane-in-tile -> coordinates.  A launch renders n_blocks LAYERS of the image and
+    // virtual tile = layer * n_tiles + tile.  In the counter-RNG mode layer b = samples [64 b, 64 b + 64) of every pixel of
+    // the frame, summed separately (the samples of a pixel are independent there); in the stream mode layer b = frame b
+    // of a batch of consecutive frames (mrt_render: frames are independent until their blend), each with its own
+    // rng_shuffle.  Usually there is one layer.
     auto locate = [&](KArgPtr C, uint32_t q, uint32_t& px, uint32_t& py, uint32_t& texel, uint32_t& layer) -> bool {
         uint32_t tile = q >> 6;
         const uint32_t l = q & 63u;
         layer = 0u;
-        if (CTR && !PILOT) { layer = tile / C->n_tiles; tile -= layer * C->n_tiles; }
+        if (!PILOT) { layer = tile / C->n_tiles; tile -= layer * C->n_tiles; }
         const uint32_t tile_x = tile % C->tiles_x, band = tile / C->tiles_x;
         const uint32_t Wc = C->locals.shape[0], Hc = C->locals.shape[1];
         px = tile_x * kTileW + (l & 7u);
@@ -864,12 +866,12 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(C->tile_queue, 1u);
             t = __builtin_amdgcn_readfirstlane(t);
-            const uint32_t n_layers = (CTR && !PILOT) ? C->n_blocks : 1u;
+            const uint32_t n_layers = PILOT ? 1u : C->n_blocks;
             if (t >= C->n_tiles * n_layers) {
                 queue_empty = true;
             } else {
                 // layer by layer, each in the heaviest-first order of the tiles
-                const uint32_t lay = (CTR && !PILOT) ? t / C->n_tiles : 0u, ti = t - lay * C->n_tiles;
+                const uint32_t lay = PILOT ? 0u : t / C->n_tiles, ti = t - lay * C->n_tiles;
                 const uint32_t tile = lay * C->n_tiles + (C->tile_order ? C->tile_order[ti] : ti);
                 uint32_t fx, fy, ft, fl;
                 const uint32_t fq = (tile << 6) | lane;
@@ -893,10 +895,13 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 base_x = (((float)px + 0.5f) - 0.5f * Wf) * pixel_side;            // fs_main :374
                 base_y = (((float)py + 0.5f) - 0.5f * Hf) * pixel_side;
                 const uint4 sd = reinterpret_cast<const uint4*>(C->seeds)[texel];     // xoshiro128plus_load :44-47
-                rng.s0 = sd.x ^ C->locals.rng_shuffle[0];
-                rng.s1 = sd.y ^ C->locals.rng_shuffle[1];
-                rng.s2 = sd.z ^ C->locals.rng_shuffle[2];
-                rng.s3 = sd.w ^ C->locals.rng_shuffle[3];
+                // the frame's rng_shuffle; in a batch of frames (stream mode) the layer's own
+                const uint32_t li = CTR ? 0u : layer;
+                rng.s0 = sd.x ^ C->layer_shuffle[li][0];
+                rng.s1 = sd.y ^ C->layer_shuffle[li][1];
+                rng.s2 = sd.z ^ C->layer_shuffle[li][2];
+                rng.s3 = sd.w ^ C->layer_shuffle[li][3];
+                if (!CTR) texel += layer * C->pix_stride;      // where this (frame, pixel)'s colour sum goes
                 color = v3(0.0f, 0.0f, 0.0f);                                         // :376
                 s_done = 0;
                 pix_trips = 0;

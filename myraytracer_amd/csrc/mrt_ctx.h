@@ -56,7 +56,7 @@ struct mrt_ctx {
         hipEvent_t render_done = nullptr, finalize_done = nullptr;
         void* d_pix_acc = nullptr;             // per-pixel (x per-block, counter mode) colour sums + costs, render -> finalize
         size_t pix_acc_layers = 0;             // capacity in layers of local_texels entries
-        uint32_t blocks = 1;                   // layers the slot's most recent frame used
+        uint32_t cost_first_layer = 0, cost_layers = 1;   // the layers holding the slot's most recent frame
         uint32_t* d_tile_cost = nullptr;       // written by this slot's finalize, orders its next queue
         uint32_t* d_tile_order = nullptr;
         uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter
@@ -87,6 +87,8 @@ struct mrt_ctx {
     hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
     uint64_t timed_frames = 0;             // redraws recorded so far
 
+    bool shuffle_overridden = false;       // mrt_set_rng_shuffle since the last frame
+    bool batch_frames = true;              // mrt_render may render several frames per launch (mrt_debug_set_frame_batching)
     float set_world_ms = 0.0f;             // host time of the last scene upload (hierarchy build + copies)
 
     std::string err;

@@ -17,6 +17,7 @@ constexpr uint32_t kMaxLevels = 4;       // levels of bounding spheres above the
 // in the test and the stored radius is kBoundInflate x the enclosing radius.
 constexpr float kBoundStretch = 1.0001f;
 constexpr double kBoundInflate = 1.015;
+constexpr uint32_t kMaxFrameBatch = 8;   // frames one render launch may cover (stream mode, mrt_render)
 constexpr uint32_t kMaxDirect = 4;       // very large spheres tested by every ray directly, outside the hierarchy
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
@@ -78,7 +79,10 @@ struct KParams {
     void* pix_acc;              // per local pixel (and per block of samples): colour sum + cost (16 B), render -> finalize
     // counter-RNG mode: a pixel's samples are independent, so the frame is n_blocks layers (block b = samples
     // [64 b, 64 b + 64)), each summed into pix_acc[b * pix_stride + texel]; finalize adds the layers in order.  1 otherwise.
+    // Stream mode: layer b = frame b of a batch of consecutive frames rendered by one launch (mrt_render), with
+    // rng_shuffle layer_shuffle[b]; layer_shuffle[0] is always the (first) frame's shuffle.
     uint32_t n_blocks, pix_stride;
+    uint32_t layer_shuffle[kMaxFrameBatch][4];
     unsigned long long* wave_log;  // diagnostic (-DMRT_STAMPS builds): 4 x u64 per wave, or null
     // mrt_debug_world_hit (the DBG instantiation of render_kernel): rays in (origin xyz, direction xyz), out: winner
     // {sphere index | -1, bits of t} per ray and the bitmap of spheres that reached the root tests

@@ -98,10 +98,10 @@ int main(int argc, char** argv) {
     }
     for (mrt_ctx* c : ctxs) TRY(c, mrt_sync(c));
     auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t f = 0; f < frames; f++) {
-        for (mrt_ctx* c : ctxs) TRY(c, mrt_redraw(c));                       // asynchronous: all GPUs render at once
-        if (n_gpus > 1) TRY(ctxs[0], mrt_gather(ctxs.data(), n_gpus, 0));     // every shard's bands -> the first GPU
-    }
+    // only the final accumulated image is wanted, so every GPU renders all its frames (mrt_render may share a launch
+    // among several frames when its shard is too small to fill the GPU) and the shards are gathered once
+    for (mrt_ctx* c : ctxs) TRY(c, mrt_render(c, frames));                   // asynchronous: all GPUs render at once
+    if (n_gpus > 1) TRY(ctxs[0], mrt_gather(ctxs.data(), n_gpus, 0));         // every shard's bands -> the first GPU
     for (mrt_ctx* c : ctxs) TRY(c, mrt_sync(c));
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const double samples = (double)args.width * args.height * args.samples_per_frame * frames;

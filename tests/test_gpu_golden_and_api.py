@@ -296,3 +296,61 @@ def test_zero_samples_per_frame_is_nan_like_the_reference(mrt, oracle):
     assert np.isnan(got[..., :3]).all() and np.isnan(ref[..., :3]).all()
     assert (got[..., 3] == 1.0).all() and (ref[..., 3] == 1.0).all()
     assert c["samples"] == 0 and c["world_hit_calls"] == 0
+
+
+@pytest.mark.parametrize("frames,max_w", [(2, 1.0), (5, 1.0), (11, 0.7)])
+def test_render_batches_frames_without_changing_them(mrt, oracle, frames, max_w):
+    """mrt_render(K) may render several consecutive frames with ONE launch (a small image cannot fill the GPU with one
+    frame's pixels): every frame keeps the rng_shuffle, the weight and the blend order it has with K x mrt_redraw -- the
+    accumulated image is bit-identical to the stepwise one and to the oracle's progressive loop."""
+    sc, cam = mrt.scene_cover(1, True)
+    w, h, spp, depth = 56, 40, 9, 50
+    ref = oracle_render(oracle, sc, cam, w, h, spp, depth, seed=8, frames=frames, max_w=max_w)
+    with mrt.State(mrt.Args(w, h, spp, depth, max_w), seed=8) as st:
+        st.set_world(sc)
+        st.set_camera(cam)
+        st.render(frames)                       # batched: up to 8 frames per launch
+        batched, cb, costs_b = st.read_framebuffer(), st.read_counters(), st.debug_read_pixel_costs()
+        assert st.frames_done == frames
+        kernels_batched = len(st.kernel_ms_history(64))
+    with mrt.State(mrt.Args(w, h, spp, depth, max_w), seed=8) as st:
+        st.set_world(sc)
+        st.set_camera(cam)
+        for _ in range(frames):
+            st.redraw()
+        stepwise, cs, costs_s = st.read_framebuffer(), st.read_counters(), st.debug_read_pixel_costs()
+        kernels_stepwise = len(st.kernel_ms_history(64))
+    assert np.array_equal(batched.view(np.uint32), ref.view(np.uint32)), mismatch_report(batched, ref)
+    assert np.array_equal(stepwise.view(np.uint32), ref.view(np.uint32))
+    for k in ("samples", "world_hit_calls", "rng_draws"):
+        assert cb[k] == cs[k]
+    assert np.array_equal(costs_b, costs_s)                      # the last frame's per-pixel costs
+    assert kernels_stepwise == frames and kernels_batched == -(-frames // 8)
+
+
+def test_render_batching_respects_overrides_and_switch(mrt):
+    """A caller-supplied rng_shuffle applies to the next frame only, which is then rendered on its own; the A/B switch turns
+    batching off; either way the images agree."""
+    sc = mrt.scene_default()
+    args = mrt.Args(48, 32, 5, 8)
+    with mrt.State(args, seed=3) as st:
+        st.set_world(sc)
+        st.set_rng_shuffle([11, 22, 33, 44])
+        st.render(4)
+        a = st.read_framebuffer()
+        n_a = len(st.kernel_ms_history(64))
+    with mrt.State(args, seed=3) as st:
+        st.set_world(sc)
+        st.set_rng_shuffle([11, 22, 33, 44])
+        for _ in range(4):
+            st.redraw()
+        b = st.read_framebuffer()
+    with mrt.State(args, seed=3) as st:
+        st.set_world(sc)
+        st.debug_set_frame_batching(False)
+        st.set_rng_shuffle([11, 22, 33, 44])
+        st.render(4)
+        c = st.read_framebuffer()
+        n_c = len(st.kernel_ms_history(64))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    assert n_a == 2 and n_c == 4              # overridden frame alone + a batch of three; four single launches
