@@ -178,7 +178,12 @@ def main():
     else:
         spheres, cam = M.scene_default(), None
 
-    stream = torch.cuda.current_stream(device)
+    # The State's passes and torch's ops (the RCCL gather, the un-permute) must be ordered on ONE stream.  torch's default
+    # stream has the handle 0, which mrt_set_stream reads as "use your own stream" -- the gather would then not wait for the
+    # frame's blend -- so the bench makes a real stream current and hands that to the State.
+    stream = torch.cuda.Stream(device)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     st = M.State(M.Args(width, height, spp, a.depth, 1.0), seed=seed, device=dev_index,
                  shard=(rank, world) if world > 1 else None, stream=stream.cuda_stream)
     st.set_world(spheres)

@@ -69,7 +69,11 @@ class _DevicePtr:
 
 
 def framebuffer_tensor(state, device: Optional[torch.device] = None) -> torch.Tensor:
-    """Zero-copy torch view of the State's most recent framebuffer ([local_rows, W, 4] f32)."""
+    """Zero-copy torch view of the State's most recent framebuffer ([local_rows, W, 4] f32).
+
+    Stream ordering is the caller's: torch ops on this tensor follow the State's redraw only if the State was created on
+    the stream they run on -- `State(..., stream=s.cuda_stream)` with a real `torch.cuda.Stream` s made current (torch's
+    default stream has handle 0, which the ABI reads as "use your own stream") -- or after `state.sync()`."""
     _, _, rows, width = state.shard_info()
     ptr = state.framebuffer_device_ptr()
     if not ptr:
