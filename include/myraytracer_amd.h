@@ -236,7 +236,7 @@ int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since c
  * device i with mrt_set_shard(ctxs[i], i, N), calling mrt_redraw on each and then ONE gather per frame. */
 
 /* One process, N contexts.  Copies every shard's most recent framebuffer into its interleaved place in the
- * root's full-frame buffer: one strided device-to-device (peer-to-peer over xGMI) copy per shard, issued on
+ * root's full-frame buffer: device-to-device (peer-to-peer over xGMI) copies of the shard's bands, issued on
  * that shard's own stream (so it follows its redraw), all links at once; the root's stream then waits for all
  * of them.  Asynchronous; read the result with mrt_read_gathered / mrt_gathered_device_ptr on ctxs[root].
  * Requires ctxs[i] to be shard i of n of the same width x height. */

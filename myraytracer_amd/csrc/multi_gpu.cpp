@@ -6,8 +6,8 @@
 // pixel index, own texel, read-only scene), so the only exchange is one gather of finished RGBA32F bands
 // per frame.  Two forms:
 //   * mrt_gather            one process, N contexts: every shard's bands are copied straight into their place
-//                           in the root's full frame by ONE strided peer-to-peer copy per shard
-//                           (hipMemcpy2DAsync over xGMI; band b of shard i lands at band b*N + i), each on its
+//                           in the root's full frame by peer-to-peer copies over xGMI (band b of shard i lands at
+//                           band b*N + i; one strided copy when shard and root share a device), each shard on its
 //                           own source stream, i.e. all peer links at once; nothing to reduce, so no ring;
 //   * mrt_gather_rccl       one process per GPU: grouped ncclSend / ncclRecv on a caller-supplied RCCL
 //                           communicator (one message per peer, straight to the root), then the same strided
@@ -45,12 +45,21 @@ int ensure_event(mrt_ctx* c) {
     return MRT_OK;
 }
 
-// bands of shard `rank` (packed, `src`) -> their interleaved places in the full frame `dst_full`, on `stream`
-hipError_t scatter_bands(float* dst_full, const float* src, uint32_t rank, uint32_t world, uint32_t local_bands,
-                         size_t bb, hipStream_t stream) {
+// bands of shard `rank` (packed, `src` on device src_dev) -> their interleaved places in the full frame `dst_full` (on
+// device dst_dev), on `stream`: one strided copy within a device, one peer copy per band (8 rows x W, 0.5 MB at C4; a few
+// dozen per frame) across devices -- the 1-D peer copy is the form every HIP runtime supports between any two GPUs
+hipError_t scatter_bands(float* dst_full, int dst_dev, const float* src, int src_dev, uint32_t rank, uint32_t world,
+                         uint32_t local_bands, size_t bb, hipStream_t stream) {
     if (local_bands == 0 || bb == 0) return hipSuccess;
-    return hipMemcpy2DAsync((char*)dst_full + (size_t)rank * bb, (size_t)world * bb, src, bb, bb, local_bands,
-                            hipMemcpyDefault, stream);
+    if (dst_dev == src_dev)
+        return hipMemcpy2DAsync((char*)dst_full + (size_t)rank * bb, (size_t)world * bb, src, bb, bb, local_bands,
+                                hipMemcpyDeviceToDevice, stream);
+    for (uint32_t b = 0; b < local_bands; b++) {
+        hipError_t e = hipMemcpyPeerAsync((char*)dst_full + ((size_t)b * world + rank) * bb, dst_dev,
+                                          (const char*)src + (size_t)b * bb, src_dev, bb, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ---- RCCL, resolved at run time ------------------------------------------------------------------
@@ -148,7 +157,7 @@ int mrt_gather(mrt_ctx* const* ctxs, uint32_t n, uint32_t root) {
         }
         // on the SOURCE's stream, i.e. after its finalize pass; the root's stream then waits for every shard
         const float* src = c->d_fb[c->target ^ 1];
-        HIP_TRY(R, scatter_bands(R->d_gather, src, i, n, c->local_bands, bb, c->stream));
+        HIP_TRY(R, scatter_bands(R->d_gather, R->device, src, c->device, i, n, c->local_bands, bb, c->stream));
         HIP_TRY(R, hipEventRecord(c->ev_gather, c->stream));
     }
     HIP_TRY(R, hipSetDevice(R->device));
@@ -196,7 +205,7 @@ int mrt_gather_rccl(mrt_ctx* c, void* nccl_comm, uint32_t root) {
     const size_t bb = band_bytes(c);
     for (uint32_t r = 0; r < world; r++) {
         const float* from = r == root ? src : c->d_gather_stage + (size_t)r * local_floats;
-        HIP_TRY(c, scatter_bands(c->d_gather, from, r, world, c->local_bands, bb, c->stream));
+        HIP_TRY(c, scatter_bands(c->d_gather, c->device, from, c->device, r, world, c->local_bands, bb, c->stream));
     }
     return MRT_OK;
 }
