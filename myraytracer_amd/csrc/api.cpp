@@ -105,6 +105,7 @@ int alloc_frame_buffers(mrt_ctx* c) {
         HIP_TRY(c, hipMalloc(&S.d_tile_cost, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&S.d_tile_order, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&S.d_sort_scratch, (1024 + 16) * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemsetAsync(S.d_sort_scratch, 0, (1024 + 16) * sizeof(uint32_t), c->stream));   // [1024] = the tile queue's counter
         HIP_TRY(c, hipMalloc(&S.d_pix_acc, (n ? n : 1) * 16));
         HIP_TRY(c, hipMemsetAsync(S.d_pix_acc, 0, (n ? n : 1) * 16, c->stream));
         S.pix_acc_layers = 1; S.cost_first_layer = 0; S.cost_layers = 1;
@@ -1015,7 +1016,8 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch) {
     // The tile queue is ordered by the per-tile cost this slot measured two frames ago, heaviest
     // first; before the slot's first frame of a scene a small pilot launch (no output) provides
     // the estimate when the frame is long enough to pay for it.  Without an estimate: index order.
-    if (c->lpt_enabled) {
+    // With no more tiles than persistent waves every tile starts at once and the order cannot matter: no pilot, no sort.
+    if (c->lpt_enabled && c->n_tiles > c->n_waves) {
         if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
             int pe = mrt::launch_render(p, true, c->n_waves, S.stream);
             if (pe) return fail(c, MRT_ERR_HIP, "pilot launch failed: %s", hipGetErrorString((hipError_t)pe));
@@ -1255,6 +1257,8 @@ int mrt_reset(mrt_ctx* c) {
     HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    for (auto& S : c->slot)          // the tile queues' counters (normally left at zero by every finalize pass)
+        if (S.d_sort_scratch) HIP_TRY(c, hipMemsetAsync(S.d_sort_scratch + 1024, 0, sizeof(uint32_t), c->stream));
     c->inputs_dirty = true;      // the next redraw's side stream waits for these memsets (ev_inputs)
     const uint32_t spp = c->locals.samples_per_frame, mode = c->locals.rng_mode;
     reset_locals(c);

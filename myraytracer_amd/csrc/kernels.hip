@@ -1011,6 +1011,8 @@ __global__ void __launch_bounds__(64) finalize_kernel(const KParams P) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o2 = __shfl_xor(cost, off); cost = cost > o2 ? cost : o2; }
     if (lane == 0 && P.tile_cost) P.tile_cost[tile] = cost;
+    // the slot's tile queue is empty again for its next render launch (which follows this pass: finalize_done)
+    if (lane == 0 && tile == 0) *P.tile_queue = 0u;
 }
 
 // Seed texture (Subject::new, lib.rs:389-415) generated on the device: SplitMix64 used as a
@@ -1048,12 +1050,11 @@ static uint32_t group_lds_bytes(const KParams& p, bool small) {
     return (small ? p.n_nodes * (uint32_t)sizeof(SphereRec) : 0u) + kWavesPerGroup * lds_wave_bytes(small, p.levels, p.gen_cap, p.mask_chunks);
 }
 
-// queue reset + the persistent render waves (pilot: + its cost-only finalize) on `stream`
+// the persistent render waves (pilot: + its cost-only finalize) on `stream`
 int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) {
     if (p.n_tiles == 0 || n_waves == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), st);
-    if (e != hipSuccess) return (int)e;
+    // (the queue counter is zero: reset at allocation and by every finalize pass of the slot)
     const bool small = scene_is_small(p);
     const uint32_t lds = group_lds_bytes(p, small);
     // persistent grid: as many workgroups as are resident with this launch's LDS footprint
