@@ -195,7 +195,7 @@ int mrt_read_seeds(mrt_ctx* ctx, uint32_t* out, size_t cap_u32);    /* this shar
 int mrt_redraw(mrt_ctx* ctx);
 /* `frames` x mrt_redraw: the same images.  Frames are independent until their blend, so when the (shard of the) image has
  * fewer than about two pixels per GPU lane -- a pixel is one sequential chain of samples, lib.rs:299-306's remedy for that is
- * more frames -- up to 8 consecutive frames of the stream mode share one render launch. */
+ * more frames -- up to 32 consecutive frames of the stream mode share one render launch (also when a frame is very short). */
 int mrt_render(mrt_ctx* ctx, uint32_t frames);
 int mrt_sync(mrt_ctx* ctx);
 /* Restart accumulation: zero framebuffers, frame counter 0, weight 0, shuffle [0;4]. */

@@ -1070,10 +1070,12 @@ int mrt_render(mrt_ctx* c, uint32_t frames) {
     if (!c) return MRT_ERR_INVALID_ARG;
     while (frames != 0) {
         uint32_t batch = 1;
-        const bool starved = c->n_tiles < 2u * c->n_waves;                 // fewer than two pixels per lane
-        if (c->batch_frames && starved && frames >= 2 && c->locals.rng_mode == MRT_RNG_PIXEL_STREAM && !c->shuffle_overridden &&
-            c->n_tiles != 0) {
-            const uint32_t want = (6u * c->n_waves + c->n_tiles - 1u) / c->n_tiles;   // about six pixels per lane (chains differ 10 x in length)
+        if (c->batch_frames && frames >= 2 && c->locals.rng_mode == MRT_RNG_PIXEL_STREAM && !c->shuffle_overridden && c->n_tiles != 0) {
+            // too few pixels to fill the GPU (fewer than two per lane): about six pixel chains per lane (they differ 10 x in length)
+            uint32_t want = c->n_tiles < 2u * c->n_waves ? (6u * c->n_waves + c->n_tiles - 1u) / c->n_tiles : 1u;
+            // too short a frame (1 spp interactive accumulation: 0.2 ms of work behind six launches): about 128 M samples per launch
+            const uint64_t per_frame = (uint64_t)c->n_tiles * 64u * std::max(c->locals.samples_per_frame, 1u);
+            want = std::max<uint64_t>(want, ((128ull << 20) + per_frame - 1) / per_frame);
             batch = std::min(std::min(frames, (uint32_t)mrt::kMaxFrameBatch), std::max(want, 1u));
         }
         int st = redraw_frames(c, batch);

@@ -17,7 +17,7 @@ constexpr uint32_t kMaxLevels = 4;       // levels of bounding spheres above the
 // in the test and the stored radius is kBoundInflate x the enclosing radius.
 constexpr float kBoundStretch = 1.0001f;
 constexpr double kBoundInflate = 1.015;
-constexpr uint32_t kMaxFrameBatch = 8;   // frames one render launch may cover (stream mode, mrt_render)
+constexpr uint32_t kMaxFrameBatch = 32;   // frames one render launch may cover (stream mode, mrt_render)
 constexpr uint32_t kMaxDirect = 4;       // very large spheres tested by every ray directly, outside the hierarchy
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
