@@ -19,7 +19,11 @@
 //     (shader.wgsl:286-296) for members with disc >= 0 and merge them into the owner's slot by a
 //     64-bit LDS minimum over (t, sphere index), which is what the reference's index-order scan yields;
 //   * persistent waves pull 8x8 tiles from one global heaviest-first queue and a lane that
-//     finishes its pixel takes the next waiting one (render_kernel);
+//     finishes its pixel takes the next waiting one (render_kernel); the queue may hold several LAYERS of the image --
+//     the frames of a batch (mrt_render), or, in the counter-RNG mode, the blocks of 64 samples of a frame -- so that a
+//     shard with few pixels, or a very short frame, still fills the chip;
+//   * an iteration is: world_hit for every lane with a ray; shading; release / refill / acquire of pixels; the next
+//     sample's camera ray for the lanes that need one, sharing the scatter's normalize;
 //   * finalize_kernel turns the per-pixel colour sums into the framebuffer: one coalesced
 //     RGBA32F store per pixel per frame, whole 128-byte lines per 8x8 tile.
 //
