@@ -47,9 +47,11 @@ WORKLOADS = {   # config c3 (default), weak scaling towards C4: n_gpus -> (width
     4: (3840, 2160, 512),
     8: (3840, 2160, 1024),
 }
-FIXED_CONFIGS = {   # BASELINE.json configs[3] / configs[4] as stated, whatever N: (scene, width, height, spp)
-    "c4": ("cover-glass", 3840, 2160, 1024),
-    "c5": ("stress", 1920, 1080, 4096),
+FIXED_CONFIGS = {   # BASELINE.json's other configs as stated, whatever N: (scene, width, height, spp, depth)
+    "c1": ("default", 400, 225, 16, 8),          # configs[0]: the reference's shipped scene (4 spheres)
+    "c2": ("cover", 1200, 675, 64, 50),          # configs[1]: cover scene, Lambertian + Metal only
+    "c4": ("cover-glass", 3840, 2160, 1024, 50), # configs[3]
+    "c5": ("stress", 1920, 1080, 4096, 50),      # configs[4]
 }
 
 
@@ -115,8 +117,12 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--scene", default="cover-glass", choices=["cover-glass", "cover", "default", "stress"])
-    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"],
-                    help="c3 (default): the headline 1920x1080x512 cover scene, weak-scaled with N; c4 / c5: BASELINE configs[3] / [4] as stated")
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="c3 (default): the headline 1920x1080x512 cover scene, weak-scaled with N; c1 / c2 / c4 / c5: BASELINE's "
+                         "configs[0] / [1] / [3] / [4] as stated")
+    ap.add_argument("--frames-per-step", type=int, default=1,
+                    help="frames one step renders through mrt_render (which may share a launch among the frames of a small or short "
+                         "frame); 1 (default) = one mrt_redraw per step")
     ap.add_argument("--rng", default=None, choices=["stream", "counter"],
                     help="stream (default for c3 / c4): the reference's one Xoshiro128+ stream per pixel per frame; counter (default for c5, "
                          "whose 8-GPU shares are pixel-starved in the stream mode): per-sample hashed states, a pixel's samples summed in "
@@ -164,10 +170,10 @@ def main():
     width, height, spp = WORKLOADS.get(a.gpus, WORKLOADS[1])
     scaling = "weak"
     if a.config in FIXED_CONFIGS:
-        a.scene, width, height, spp = FIXED_CONFIGS[a.config]
+        a.scene, width, height, spp, a.depth = FIXED_CONFIGS[a.config]
         scaling = "strong"
-    headline = (not (a.width or a.height or a.spp) and a.depth == 50 and a.rng == ("counter" if a.config == "c5" else "stream") and
-                ((a.config == "c3" and a.scene == "cover-glass" and a.gpus in WORKLOADS) or a.config in FIXED_CONFIGS))
+    headline = (not (a.width or a.height or a.spp) and a.frames_per_step == 1 and a.rng == ("counter" if a.config == "c5" else "stream") and
+                ((a.config == "c3" and a.scene == "cover-glass" and a.depth == 50 and a.gpus in WORKLOADS) or a.config in FIXED_CONFIGS))
     width, height, spp = a.width or width, a.height or height, a.spp or spp
     seed = 1
     if a.scene == "cover-glass":
@@ -198,7 +204,10 @@ def main():
     staging = torch.empty((world, lrows, width, 4), dtype=torch.float32, device=gather_device) if (use_dist and rank == 0) else None
 
     def step():
-        st.redraw()                                    # async on torch's current stream
+        if a.frames_per_step == 1:
+            st.redraw()                                # async on torch's current stream
+        else:
+            st.render(a.frames_per_step)
         if use_dist:
             local = mdist.framebuffer_tensor(st, device)
             if backend != "nccl":
@@ -217,7 +226,7 @@ def main():
     # in tests/golden/fullsize_rows.json (C3): when this run renders that workload, its first frame must reproduce them
     first_frame_check = None
     golden = None
-    if world == 1 and headline and a.config == "c3" and a.warmup > 0:      # (the checked frame is the first warm-up step)
+    if world == 1 and headline and a.config == "c3" and a.warmup > 0 and a.frames_per_step == 1:      # (the checked frame is the first warm-up step)
         try:
             golden = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_rows.json")))["configs"]["c3"]["frame0_counters"]
         except Exception:
@@ -296,7 +305,7 @@ def main():
         rank_devices = [{"rank": 0, "local_rank": local_rank, "device": torch.cuda.get_device_name(device)}]
 
     if rank == 0:
-        total_samples = float(width) * height * spp * a.steps
+        total_samples = float(width) * height * spp * a.steps * a.frames_per_step
         assert samples_counted == total_samples or a.steps == 0, (samples_counted, total_samples)
         value = total_samples / elapsed_max * 1e-6
         n_spheres = len(spheres)
@@ -329,7 +338,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.config.upper() if (headline or a.rng == 'counter') else 'custom'}: {scene_names[a.scene]} ({n_spheres} spheres, scene_seed 1), "
                                    f"{width}x{height}, {spp} spp per frame, depth {a.depth}, seed {seed}; "
-                                   f"1 step = 1 redraw (+ RCCL gather to rank 0 when n_gpus > 1)",
+                                   f"1 step = {a.frames_per_step} redraw(s) (+ RCCL gather to rank 0 when n_gpus > 1)",
                        "headline": headline, "sharding": f"interleaved 8-row bands over {world} GPU(s)",
                        "rng": {"stream": "one Xoshiro128+ stream per pixel per frame (the reference's, shader.wgsl:377-382)",
                                "counter": "per-sample hashed states, blocks of 64 samples (extension)"}[a.rng]},
