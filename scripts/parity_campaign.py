@@ -55,26 +55,27 @@ def main():
         if mode and rng.random() < 0.4:
             spp, w, h = int(rng.choice([64, 65, 130, 200])), min(w, 24), min(h, 16)
         seed = int(rng.integers(0, 2 ** 62))
+        frames = int(rng.choice([1, 1, 2, 5])) if spp <= 5 else 1          # several frames go through mrt_render's batches
         hier = (int(rng.integers(1, 5)), int(rng.choice([1, 4, 16, 64, 256])))
         lim = max(float(np.abs(sc["center"]).max()), float(np.abs(sc["radius"]).max()))
         if lim > 5e6:            # the ABI rejects |v| > 1e7
             skipped += 1
             continue
         cnt = O.Counters()
-        ref = oracle_render(O, sc, cam, w, h, spp, depth, seed, 1, 1.0, counters=cnt, rng_mode=mode)
+        ref = oracle_render(O, sc, cam, w, h, spp, depth, seed, frames, 1.0, counters=cnt, rng_mode=mode)
         with M.State(M.Args(w, h, spp, depth, 1.0), seed=seed) as st:
             st.debug_set_hierarchy(*hier)
             st.debug_set_sweep(int(rng.integers(0, 3)))      # automatic / VALU / matrix-core sweep
             st.set_world(sc)
             if cam is not None: st.set_camera(cam)
             st.set_rng_mode(mode)
-            st.render(1)
+            st.render(frames)
             got, c = st.read_framebuffer(), st.read_counters()
         same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
         ok = same.all() and c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws
         if not ok:
             fails += 1
-            print(f"FAIL case {case}: n={n} {w}x{h}x{spp} depth {depth} rng_mode {mode} hier {hier} scale {scale:.3g}: {mismatch_report(got, ref)}", flush=True)
+            print(f"FAIL case {case}: n={n} {w}x{h}x{spp} depth {depth} rng_mode {mode} frames {frames} hier {hier} scale {scale:.3g}: {mismatch_report(got, ref)}", flush=True)
         if (case - first) % 25 == 24:
             print(f"... {case - first + 1} cases, {fails} failures, {time.time() - t0:.0f} s", flush=True)
     print(f"campaign: {n_cases} cases ({skipped} skipped: out of the ABI's coordinate range), {fails} failures")
