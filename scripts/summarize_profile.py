@@ -27,9 +27,10 @@ for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
         if targs[1] == "false":                                                                   # skip the PILOT instantiation
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        vals[k] = sum(v) / len(v)
-        launches[k] = len(v)
-out = {"source": f"gpurun_out/prof_{tag} (scripts/profile.sh: separate rocprofv3 --pmc passes)", "per_launch_mean": vals,
+        v = sorted(v)
+        vals[k] = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])     # median: the counters are
+        launches[k] = len(v)           # device-wide, and a launch now and then picks up a neighbour's traffic (one WRITE_SIZE sample of 6 x the rest)
+out = {"source": f"gpurun_out/prof_{tag} (scripts/profile.sh: separate rocprofv3 --pmc passes); medians over the launches", "per_launch_median": vals,
        "launches_averaged": launches}
 if "GRBM_GUI_ACTIVE" in vals:
     cyc = vals["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
