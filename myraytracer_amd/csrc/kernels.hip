@@ -90,15 +90,6 @@ __device__ __forceinline__ float rng_pm1(Rng& r) {
     r.draws++;
     return __builtin_fmaf((float)rng_next(r), 0x1p-31f, -1.0f);
 }
-__device__ __forceinline__ V3 rng_unit_ball(Rng& r) {            // shader.wgsl:84-90
-    V3 v;
-    do {
-        const float x = rng_pm1(r), y = rng_pm1(r), z = rng_pm1(r);          // :77-82 order x,y,z
-        v = v3(x, y, z);
-    } while (dot3(v, v) > 1.0f);
-    return v;
-}
-
 // The reference's literal acceptance test, for the index-ordered loop over ALL spheres that rays
 // with a non-finite or non-unit direction take: NaN compares false, so a NaN root is accepted.
 __device__ __forceinline__ void literal_test(const SphereRec s, uint32_t idx, V3 o, V3 d, float a,
@@ -433,7 +424,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         // the new camera ray and the scattered rays share one normalize (:354 / :381) and every lane enters the next
         // world_hit with a ray.  The wave's first iteration has nothing to trace and only acquires.  Per lane the draw
         // order is the reference's: jitter, lens, then the path's draws.
-        auto new_sample = [&](V3& nd) {
+        // returns whether the lane still needs a point of the lens disk (new_sample_lens finishes the ray then)
+        auto new_sample_head = [&](V3& nd, V3& p) -> bool {
             if (CTR) {      // extension: this sample's state = hash(pixel frame state, sample index)
                 // (the pixel's frame state -- seed texel ^ shuffle, :44-47 -- is re-read per sample rather than held in
                 // four more registers across the whole bounce loop)
@@ -452,37 +444,34 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             float vx = base_x + u * pixel_side;
             float vy = base_y + v * pixel_side;
             const KArgPtr C = cold_args();
+            att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
+            depth_left = C->locals.ray_depth;
             if (C->cam.mode == 0) {
                 o = v3(0.0f, 0.0f, 0.0f);                               // ORIGIN, :361
                 nd = v3(vx, vy, -1.0f);                                 // :381 before normalize()
-            } else {
-                // extension: look-at thin-lens camera over the same (vx, vy)
-                V3 p = v3((vx * C->cam.su[0] + vy * C->cam.sv[0]) - C->cam.fw[0],
-                          (vx * C->cam.su[1] + vy * C->cam.sv[1]) - C->cam.fw[1],
-                          (vx * C->cam.su[2] + vy * C->cam.sv[2]) - C->cam.fw[2]);
-                o = v3(C->cam.origin[0], C->cam.origin[1], C->cam.origin[2]);
-                if (C->cam.defocus) {
-                    float lx, ly;
-                    do {                                                // unit disk by rejection
-                                    lx = rng_pm1(rng); ly = rng_pm1(rng);
-                    } while (__builtin_fmaf(ly, ly, lx * lx) > 1.0f);
-                    V3 off = v3(lx * C->cam.ru[0] + ly * C->cam.rv[0],
-                                lx * C->cam.ru[1] + ly * C->cam.rv[1],
-                                lx * C->cam.ru[2] + ly * C->cam.rv[2]);
-                    o = o + off;
-                    nd = p - off;
-                } else {
-                    nd = p;
-                }
+                return false;
             }
-            att = v3(1.0f, 1.0f, 1.0f);                                 // color_world :337
-            depth_left = C->locals.ray_depth;
+            // extension: look-at thin-lens camera over the same (vx, vy)
+            p = v3((vx * C->cam.su[0] + vy * C->cam.sv[0]) - C->cam.fw[0],
+                   (vx * C->cam.su[1] + vy * C->cam.sv[1]) - C->cam.fw[1],
+                   (vx * C->cam.su[2] + vy * C->cam.sv[2]) - C->cam.fw[2]);
+            o = v3(C->cam.origin[0], C->cam.origin[1], C->cam.origin[2]);
+            nd = p;
+            return C->cam.defocus != 0;
+        };
+        auto new_sample_lens = [&](V3& nd, V3 p, float lx, float ly) {      // (lx, ly): the accepted point of the unit disk
+            const KArgPtr C = cold_args();
+            const V3 off = v3(lx * C->cam.ru[0] + ly * C->cam.rv[0],
+                              lx * C->cam.ru[1] + ly * C->cam.rv[1],
+                              lx * C->cam.ru[2] + ly * C->cam.rv[2]);
+            o = o + off;
+            nd = p - off;
         };
         trips++;
-        if (live) pix_trips++;
 
         // ------------------------------------------------------------ world_hit, shader.wgsl:314-329
         const bool trace = live && depth_left != 0u;                        // lanes inside the loop of :339
+        if (trace) pix_trips++;
         if (COUNT) bounces += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(trace));
         float t_sup = 1.0e4f;                                               // :340
         int32_t best = -1;
@@ -759,97 +748,20 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             task_done = true;
         }
 
+        // ---- paths that end without a scatter: loop :339 not entered (depth exhausted, :357) or a miss (sky, :343-345).
+        // They are known before any shading, so these lanes release / start their next sample in this very iteration and
+        // their camera-ray draws share the rejection loop below with the hit lanes' unit-ball draws.
         bool start_sample = false;
         V3 ndir = d;
-        if (!DBG && live) {
-            bool path_done = false;
-            V3 contrib = v3(0.0f, 0.0f, 0.0f);
-            if (depth_left == 0u) {
-                path_done = true;                                           // loop :339 not entered -> :357
-            } else {
-                if (best < 0) {
-                    // color_sky, shader.wgsl:331-334, 343-345
-                    float t = 0.5f * d.y + 0.5f;
-                    contrib = att * v3(mixf(1.0f, 0.5f, t), mixf(1.0f, 0.7f, t), mixf(1.0f, 1.0f, t));
-                    path_done = true;
-                } else {
-                    // rest of sphere_hit for the winning sphere, shader.wgsl:298-309
-                    // (centre, radius) and (material colour, fuzz | ior) of sphere `best` come packed in two
-                    // 16-byte records built at upload from the reference's SoA arrays (sphere_load_* :254-268,
-                    // albedo / fuzz loads :205, :232-240): the same bits, one round trip instead of a chain of four.
-                    const KArgPtr C = cold_args();
-                    const float4 sh0 = reinterpret_cast<const float4*>(C->shade)[2 * best];
-                    const float4 sh1 = reinterpret_cast<const float4*>(C->shade)[2 * best + 1];
-                    const int32_t m_ty = C->i32_data[C->world.spheres.material_ty_base_idx + best];
-                    const V3 center = v3(sh0.x, sh0.y, sh0.z);
-                    const float radius = sh0.w;
-                    const V3 at = o + t_sup * d;                            // ray_normalized_at :103-105
-                    V3 normal = (at - center) / radius;
-                    const bool front_face = dot3(normal, d) <= 0.0f;
-                    if (!front_face) normal = -normal;
-
-                    // dyn_material_scatter, shader.wgsl:244-252
-                    V3 albedo = v3(sh1.x, sh1.y, sh1.z);
-                    bool scattered;
-                    // Lambertian and Metal both start with one unit-ball sample (:209 via :92-94, :236): one
-                    // rejection loop for the lanes of either kind (each lane still draws only its own numbers)
-                    const bool is_lambertian = m_ty == MRT_LAMBERTIAN, is_metal = m_ty == MRT_METAL;
-                    V3 ball = v3(0.0f, 0.0f, 0.0f);
-                    if (is_lambertian || is_metal) ball = rng_unit_ball(rng);
-                    if (is_lambertian) {                                    // :203-216
-                        ndir = normal + normalize3(ball);                   // unit_sphere :92-94
-                        if (dot3(ndir, ndir) == 0.0f) ndir = normal;
-                        scattered = true;
-                    } else if (is_metal) {                                  // :228-242
-                        const V3 refl = reflect3(d, normal);
-                        const float fuzz = sh1.w;
-                        ndir = v3(refl.x + fuzz * ball.x, refl.y + fuzz * ball.y, refl.z + fuzz * ball.z);
-                        scattered = !(dot3(ndir, normal) <= 0.0f);
-                    } else if (m_ty == MRT_DIELECTRIC) {                    // extension, DESIGN.md §3
-                        // The quantities that depend on the sphere alone come from its shading record, evaluated by
-                        // the host with the same f32 operations (api.cpp): 1/ior and ((1-ri)/(1+ri))^2 for ri = 1/ior
-                        // (front face) and ri = ior (back face).  The attenuation of a Dielectric is (1,1,1).
-                        const float ior = sh1.w;
-                        const float ri = front_face ? sh1.x : ior;
-                        const float r0 = front_face ? sh1.y : sh1.z;
-                        albedo = v3(1.0f, 1.0f, 1.0f);
-                        float cos_t = dot3(-d, normal);
-                        cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;
-                        const float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
-                        const bool cannot_refract = (ri * sin_t) > 1.0f;
-                        const float x1 = 1.0f - cos_t;
-                        const float x2 = x1 * x1; const float x4 = x2 * x2; const float x5 = x4 * x1;
-                        const float reflectance = r0 + (1.0f - r0) * x5;
-                        const float u = rng_f32(rng);                       // always exactly one draw
-                        if (cannot_refract || reflectance > u) {
-                            ndir = reflect3(d, normal);
-                        } else {
-                            const V3 perp = v3(ri * (d.x + cos_t * normal.x), ri * (d.y + cos_t * normal.y),
-                                               ri * (d.z + cos_t * normal.z));
-                            const float k = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
-                            ndir = v3(perp.x + k * normal.x, perp.y + k * normal.y, perp.z + k * normal.z);
-                        }
-                        scattered = true;
-                    } else {
-                        scattered = false;                                  // :249-251
-                    }
-
-                    if (!scattered) {
-                        path_done = true;                                   // :349-351 -> vec3(0)
-                    } else {
-                        att = att * albedo;                                 // :353
-                        o = at;
-                        depth_left--;
-                        if (depth_left == 0u) path_done = true;             // loop ends -> :357 vec3(0)
-                    }
-                }
-            }
-
-            if (path_done) {
-                color = color + contrib;                                    // :381
-                s_done++;
-                if (s_done < (CTR ? (blk & 127u) : spp)) start_sample = true; else task_done = true;
-            }
+        const bool hit = !DBG && live && depth_left != 0u && best >= 0;
+        if (!DBG && live && !hit) {
+            if (depth_left != 0u) {
+                // color_sky, shader.wgsl:331-334, 343-345
+                float t = 0.5f * d.y + 0.5f;
+                color = color + att * v3(mixf(1.0f, 0.5f, t), mixf(1.0f, 0.7f, t), mixf(1.0f, 1.0f, t));     // :381
+            }                                                                   // else: + vec3(0), :357
+            s_done++;
+            if (s_done < (CTR ? (blk & 127u) : spp)) start_sample = true; else task_done = true;
         }
         MRT_STAMP(4);
 
@@ -938,7 +850,91 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         MRT_STAMP(5);
 
         if (!DBG) {
-            if (start_sample) new_sample(ndir);
+            // -- (a) lanes starting a sample: jitter and camera point (shader.wgsl:378-381); the lens-disk draws follow below
+            V3 cam_p = v3(0.0f, 0.0f, 0.0f);
+            bool need_lens = false;
+            if (start_sample) need_lens = new_sample_head(ndir, cam_p);
+            // -- (b) lanes with a hit: the rest of sphere_hit for the winning sphere (:298-309) and the material's own part
+            // (centre, radius) and (material colour, fuzz | ior) of sphere `best` come packed in two 16-byte records built
+            // at upload from the reference's SoA arrays (sphere_load_* :254-268, albedo / fuzz loads :205, :232-240): the
+            // same bits, one round trip instead of a chain of four.
+            V3 normal = v3(0.0f, 0.0f, 0.0f), refl = v3(0.0f, 0.0f, 0.0f);
+            float fuzz = 0.0f;
+            bool is_lambertian = false, is_metal = false;
+            if (hit) {
+                const KArgPtr C = cold_args();
+                const float4 sh0 = reinterpret_cast<const float4*>(C->shade)[2 * best];
+                const float4 sh1 = reinterpret_cast<const float4*>(C->shade)[2 * best + 1];
+                const int32_t m_ty = C->i32_data[C->world.spheres.material_ty_base_idx + best];
+                const V3 center = v3(sh0.x, sh0.y, sh0.z);
+                const float radius = sh0.w;
+                const V3 at = o + t_sup * d;                            // ray_normalized_at :103-105
+                normal = (at - center) / radius;
+                const bool front_face = dot3(normal, d) <= 0.0f;
+                if (!front_face) normal = -normal;
+                // dyn_material_scatter, shader.wgsl:244-252
+                is_lambertian = m_ty == MRT_LAMBERTIAN;
+                is_metal = m_ty == MRT_METAL;
+                if (is_lambertian || is_metal) {
+                    att = att * v3(sh1.x, sh1.y, sh1.z);                    // :353 (moot if the scatter fails: the path ends)
+                    if (is_metal) { refl = reflect3(d, normal); fuzz = sh1.w; }     // :230, :232
+                } else if (m_ty == MRT_DIELECTRIC) {                        // extension, DESIGN.md §3
+                    // The quantities that depend on the sphere alone come from its shading record, evaluated by
+                    // the host with the same f32 operations (api.cpp): 1/ior and ((1-ri)/(1+ri))^2 for ri = 1/ior
+                    // (front face) and ri = ior (back face).  The attenuation of a Dielectric is (1,1,1).
+                    const float ior = sh1.w;
+                    const float ri = front_face ? sh1.x : ior;
+                    const float r0 = front_face ? sh1.y : sh1.z;
+                    float cos_t = dot3(-d, normal);
+                    cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;
+                    const float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+                    const bool cannot_refract = (ri * sin_t) > 1.0f;
+                    const float x1 = 1.0f - cos_t;
+                    const float x2 = x1 * x1; const float x4 = x2 * x2; const float x5 = x4 * x1;
+                    const float reflectance = r0 + (1.0f - r0) * x5;
+                    const float u = rng_f32(rng);                       // always exactly one draw
+                    if (cannot_refract || reflectance > u) {
+                        ndir = reflect3(d, normal);
+                    } else {
+                        const V3 perp = v3(ri * (d.x + cos_t * normal.x), ri * (d.y + cos_t * normal.y),
+                                           ri * (d.z + cos_t * normal.z));
+                        const float k = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
+                        ndir = v3(perp.x + k * normal.x, perp.y + k * normal.y, perp.z + k * normal.z);
+                    }
+                } else {
+                    depth_left = 1u;                                        // :249-251: no scatter -> the path ends below
+                    ndir = d;
+                }
+                o = at;
+            }
+            // -- (c) ONE rejection loop for both kinds of lanes (each lane draws only its own numbers, in its own order):
+            // Lambertian / Metal lanes a point of the unit ball (:84-90: three draws per try), lanes starting a sample
+            // under a defocusing camera a point of the unit disk (two draws per try; z = 0 leaves the test's value as it is)
+            const bool need_ball = is_lambertian || is_metal;
+            float bx = 0.0f, by = 0.0f, bz = 0.0f;
+            if (need_ball || need_lens) {
+                do {
+                    bx = rng_pm1(rng); by = rng_pm1(rng);                                 // :77-82 order x, y, z
+                    bz = 0.0f;
+                    if (need_ball) bz = rng_pm1(rng);
+                } while (__builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx)) > 1.0f);
+            }
+            // -- (d) what the draws are for
+            if (need_lens) new_sample_lens(ndir, cam_p, bx, by);
+            if (hit) {
+                bool scattered = true;
+                if (is_lambertian) {                                    // :203-216
+                    ndir = normal + normalize3(v3(bx, by, bz));             // unit_sphere :92-94
+                    if (dot3(ndir, ndir) == 0.0f) ndir = normal;
+                } else if (is_metal) {                                  // :228-242
+                    ndir = v3(refl.x + fuzz * bx, refl.y + fuzz * by, refl.z + fuzz * bz);
+                    scattered = !(dot3(ndir, normal) <= 0.0f);
+                }
+                // A failed scatter (:349-351) or the last allowed bounce (:339's loop ends, :357) ends the path with
+                // vec3(0): the lane enters the next iteration with nothing left to trace and is accounted there, with the
+                // paths that miss (one iteration later than a miss would be; rare at any depth worth rendering).
+                depth_left = scattered ? depth_left - 1u : 0u;
+            }
             // normalize() of the scattered direction (:354) and of the new sample's camera ray (:381), one code
             // path for the lanes of either kind
             if (has_task && !task_done) d = normalize3(ndir);
