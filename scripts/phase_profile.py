@@ -16,12 +16,13 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     st.render(1); st.sync()
     raw = (C.c_uint64 * 16)()
     _lib.load().mrt_debug_read_counters(st._ctx, raw)
-    names = ["new_sample", "sweep", "walk: node rounds", "walk: root rounds", "shade", "release/refill/acquire"]
+    names = ["tail: camera rays, hit records, rejection loop, scatter, normalize", "sweep", "walk: node rounds", "walk: root rounds",
+             "paths ending without a scatter", "release/refill/acquire"]
     ph = [raw[6 + k] for k in range(6)] + [raw[5]]
     names = names + ["walk: owners unpack masks into items"]
     tot = sum(ph)
     print("kernel ms", st.last_kernel_ms(), "wave sweeps", raw[3] / 64)
     for n, v in zip(names, ph):
-        print(f"{n:32s} {v / max(1, tot):7.3%}  cycles/wave-iteration {v / (raw[3] / 64):9.1f}")
+        print(f"{n:70s} {v / max(1, tot):7.3%}  cycles/wave-iteration {v / (raw[3] / 64):9.1f}")
     sweeps = raw[3] / 64
     print(f"node rounds/sweep {raw[12] / sweeps:.2f} (items/round {raw[14] / max(1, raw[12]):.1f}), root rounds/sweep {raw[13] / sweeps:.2f} (items/round {raw[15] / max(1, raw[13]):.1f})")
