@@ -508,8 +508,9 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, nr2)));
                     const float disc = __builtin_fmaf(bq, bq, -(a * cq));
                     // (not queued when the sphere is entirely behind the origin: see the node rounds)
-                    const bool hq = usable && !(disc < 0.0f) && ((__float_as_uint(bq) | __float_as_uint(cq)) >> 31) != 0u;
-                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(hq);
+                    const bool cand = !(disc < 0.0f), ahead = (int32_t)(__float_as_uint(bq) | __float_as_uint(cq)) < 0;
+                    const bool hq = usable && cand && ahead;
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(usable) & __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(ahead);
                     if (hq) queues[n_hits0 + rank_in(mk)] = (entry_t)((lane << kIdBits) | (C->direct_first + j));
                     n_hits0 += (uint32_t)__popcll(mk);
                 }
@@ -652,6 +653,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         const SphereRec* const ch = nodes + cbase + 4u * node;
                         const uint32_t rot = node >> 2;
                         bool h[4];
+                        unsigned long long hm[4];
                         {
                             const SphereRec sr[4] = {ch[rot & 3u], ch[(rot + 1u) & 3u], ch[(rot + 2u) & 3u], ch[(rot + 3u) & 3u]};
 #pragma unroll
@@ -665,8 +667,11 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                 // and fail t >= 0.001 (:291) -- can never be the hit; for a bound (1.5 % larger than what it
                                 // encloses) the same holds for everything inside it.  Dropping it here saves its root test /
                                 // its subtree; it does not change the winner.  Sign bits: both >= +0.
-                                const bool ahead = ((__float_as_uint(bq) | __float_as_uint(cq)) >> 31) != 0u;
-                                h[q] = !(disc < 0.0f) && ahead;
+                                const bool cand = !(disc < 0.0f), ahead = (int32_t)(__float_as_uint(bq) | __float_as_uint(cq)) < 0;
+                                h[q] = cand && ahead;
+                                // (one ballot per comparison, combined on the scalar side: a ballot of their conjunction
+                                // would first be materialised per lane)
+                                hm[q] = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(ahead);
                             }
                         }
                         uint32_t dn = 0;
@@ -678,7 +683,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         const unsigned long long act_mask = take >= 64u ? ~0ull : ((1ull << take) - 1ull);
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const unsigned long long mk = __builtin_amdgcn_ballot_w64(h[q]) & act_mask;
+                            const unsigned long long mk = hm[q] & act_mask;
                             if (h[q] && act) dst[pushed + rank_in(mk)] = (entry_t)(e0 + ((rot + (uint32_t)q) & 3u));
                             pushed += (uint32_t)__popcll(mk);
                         }
