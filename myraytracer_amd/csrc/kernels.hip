@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     // (not queued when the sphere is entirely behind the origin: see the node rounds)
                     const bool cand = !(disc < 0.0f), ahead = (int32_t)(__float_as_uint(bq) | __float_as_uint(cq)) < 0;
                     const bool hq = usable && cand && ahead;
-                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(usable) & __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(ahead);
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(hq);
                     if (hq) queues[n_hits0 + rank_in(mk)] = (entry_t)((lane << kIdBits) | (C->direct_first + j));
                     n_hits0 += (uint32_t)__popcll(mk);
                 }
