@@ -667,11 +667,11 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                 // and fail t >= 0.001 (:291) -- can never be the hit; for a bound (1.5 % larger than what it
                                 // encloses) the same holds for everything inside it.  Dropping it here saves its root test /
                                 // its subtree; it does not change the winner.  Sign bits: both >= +0.
-                                const bool cand = !(disc < 0.0f), ahead = (int32_t)(__float_as_uint(bq) | __float_as_uint(cq)) < 0;
-                                h[q] = cand && ahead;
-                                // (one ballot per comparison, combined on the scalar side: a ballot of their conjunction
-                                // would first be materialised per lane)
-                                hm[q] = __builtin_amdgcn_ballot_w64(cand) & __builtin_amdgcn_ballot_w64(ahead);
+                                // Both conditions from sign bits, in one three-input bit operation and one comparison: the
+                                // discriminant of a finite ray against finite geometry is never NaN, and never -0 (b*b - a*c
+                                // cancels to +0), so "not < 0" is "sign bit clear".
+                                h[q] = (int32_t)((__float_as_uint(bq) | __float_as_uint(cq)) & ~__float_as_uint(disc)) < 0;
+                                hm[q] = __builtin_amdgcn_ballot_w64(h[q]);
                             }
                         }
                         uint32_t dn = 0;
