@@ -343,7 +343,10 @@ constexpr uint32_t kWavesPerGroup = 4;
 // is ray number `texel` of P.dbg_rays, traced once; the winner goes to P.dbg_hit and every (ray, sphere) that
 // reaches the root tests is recorded in P.dbg_cand.  Nothing else of the kernel changes.
 template <bool COUNT, bool PILOT, bool CTR, bool SMALL, bool MFMA, bool DBG = false>
-__global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(5, 8))) render_kernel(const KParams P) {
+// Registers: small scenes run 5 workgroups per CU (their LDS footprint, 31.5 KB at C3) = 5 waves per SIMD = 96 VGPRs; large
+// scenes (work queues of every level, u32 items: 33-36 KB per workgroup) fit 4 workgroups per CU whatever the kernel does, so
+// they may use the 128 VGPRs of 4 waves per SIMD instead of spilling at 96.
+__global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(SMALL ? 5 : 4, 8))) render_kernel(const KParams P) {
     typedef typename Ent<SMALL>::type entry_t;
     constexpr uint32_t kIdBits = Ent<SMALL>::id_bits;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1065,7 +1068,8 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
     // persistent grid: as many workgroups as are resident with this launch's LDS footprint
     // (n_waves comes from the register-limited occupancy)
     {
-        const uint32_t per_cu = (160u * 1024u) / lds;
+        uint32_t per_cu = (160u * 1024u) / lds;
+        if (!small && per_cu > 4u) per_cu = 4u;         // the large-scene kernels are built for 4 waves per SIMD (render_kernel)
         const uint32_t cap = p.cus * per_cu * kWavesPerGroup;
         if (cap < n_waves) n_waves = cap;
     }
@@ -1102,7 +1106,8 @@ int launch_debug_world_hit(const KParams& p, uint32_t n_waves, void* stream) {
     if (e != hipSuccess) return (int)e;
     const bool small = scene_is_small(p);
     const uint32_t lds = group_lds_bytes(p, small);
-    const uint32_t per_cu = (160u * 1024u) / lds;
+    uint32_t per_cu = (160u * 1024u) / lds;
+    if (!small && per_cu > 4u) per_cu = 4u;
     const uint32_t cap = p.cus * per_cu * kWavesPerGroup;
     if (cap < n_waves) n_waves = cap;
     const uint32_t want = n_waves < p.n_tiles ? n_waves : p.n_tiles;
