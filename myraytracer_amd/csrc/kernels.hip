@@ -645,8 +645,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         // for the cluster's members; members with disc >= 0 become (owner, member) items.
                         // k >= 2: the sweep's conservative test on the child bounds (the same expression with
                         // the direction stretched and a = 1, bit for bit test1()); passing children become items.
-                        // Read q takes child (q + node/4) % 4, so that the 64 lanes of one read spread
-                        // over all 16 LDS slots (4 banks each) instead of the 4 that child q alone maps to.
+                        // (Round 1 rotated the four reads by node/4 to spread one read's 64 lanes over all LDS banks; the 8
+                        // VALU of address arithmetic per round cost more than the bank conflicts they avoided: round 2.)
                         const bool inner = kLvMax >= 2 && k >= 2;
                         const float sc = inner ? kBoundStretch : 1.0f, ra_eff = inner ? 1.0f : ra;
                         const V3 re = v3(rd.x * sc, rd.y * sc, rd.z * sc);
@@ -654,11 +654,10 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
 #pragma unroll
                         for (int lv = 1; lv < kLvMax; lv++) cbase = (k - 1 == lv) ? P.level_base[lv] : cbase;
                         const SphereRec* const ch = nodes + cbase + 4u * node;
-                        const uint32_t rot = node >> 2;
                         bool h[4];
                         unsigned long long hm[4];
                         {
-                            const SphereRec sr[4] = {ch[rot & 3u], ch[(rot + 1u) & 3u], ch[(rot + 2u) & 3u], ch[(rot + 3u) & 3u]};
+                            const SphereRec sr[4] = {ch[0], ch[1], ch[2], ch[3]};
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
                                 const float ocx = ro.x - sr[q].cx, ocy = ro.y - sr[q].cy, ocz = ro.z - sr[q].cz;
@@ -687,7 +686,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             const unsigned long long mk = hm[q] & act_mask;
-                            if (h[q] && act) dst[pushed + rank_in(mk)] = (entry_t)(e0 + ((rot + (uint32_t)q) & 3u));
+                            if (h[q] && act) dst[pushed + rank_in(mk)] = (entry_t)(e0 + (uint32_t)q);
                             pushed += (uint32_t)__popcll(mk);
                         }
 #pragma unroll
