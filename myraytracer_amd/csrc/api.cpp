@@ -876,6 +876,10 @@ int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
     mrt_camera_raw raw;
     int st = mrt_camera_derive(cam, &raw);
     if (st != MRT_OK) return fail(c, st, "mrt_set_camera: degenerate or invalid camera");
+    // like the geometry (mrt_set_world_raw): moderate, so that no discriminant of a camera ray can overflow
+    for (int k = 0; k < 3; k++)
+        if (raw.mode != 0 && !(std::fabs(raw.origin[k]) <= 1.0e7f && std::fabs(raw.ru[k]) <= 1.0e7f && std::fabs(raw.rv[k]) <= 1.0e7f))
+            return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_camera: |lookfrom| or the lens radius exceeds 1e7");
     c->cam_raw = raw;
     for (auto& S : c->slot) S.cost_valid = false;
     return MRT_OK;
@@ -1163,6 +1167,8 @@ int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_ou
     const size_t need_words = ((size_t)c->n_spheres + 31) / 32;
     if (cand_out && cand_words < need_words) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_world_hit: need %zu bitmap words per ray", need_words);
     if (n > (1u << 26)) return fail(c, MRT_ERR_INVALID_ARG, "mrt_debug_world_hit: too many rays");
+    for (size_t i = 0; i < 6 * n; i++)
+        if (!(std::fabs(rays[i]) <= 2.0e7f)) return fail(c, MRT_ERR_INVALID_ARG, "mrt_debug_world_hit: ray %zu is not finite or beyond 2e7", i / 6);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, sync_all(c));
     // rays become the texels of an 8-pixel-wide virtual image (one 8x8 tile per 64 rays), padded with copies of ray 0

@@ -484,9 +484,11 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             // reference treats as "not < 0".  Such lanes take the literal loop below.
             // So does a direction that is not (nearly) unit length -- normalize() of an overflowed or
             // zero vector -- for which the sweep's conservative test has no proof.
-            const bool weird = !(__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z) +
-                                 __builtin_fabsf(d.x) + __builtin_fabsf(d.y) + __builtin_fabsf(d.z) < __builtin_inff()) ||
-                               !(a > 0.99999f && a < 1.00001f);
+            // One test covers both: a non-finite direction gives a non-finite `a`, and an origin is non-finite only
+            // together with its direction -- origins are the camera's (validated: finite, |v| <= 1e7) or a hit point
+            // o + t d of a finite ray and t < 1e4, and a hit point that is not finite makes the normal, hence the
+            // scattered direction, NaN in the same iteration.
+            const bool weird = !(a > 0.99999f && a < 1.00001f);
             const bool usable = trace && !weird;
             const V3 ds = v3(d.x * kBoundStretch, d.y * kBoundStretch, d.z * kBoundStretch);
             // every lane leaves its ray where whoever picks up one of its work items finds it
