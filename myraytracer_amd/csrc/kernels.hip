@@ -263,6 +263,7 @@ __device__ __forceinline__ uint32_t mfma_sweep_tile(const u32x4 a, const MfmaRay
 #define MRT_STAMP(k) do { } while (0)
 #endif
 
+constexpr int kUnpackMore = 1;            // extra records unpacked per trip of the owners' loop (1, 2, 3 measured alike)
 constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 spheres per sweep block
 
 // The cooperative walk: candidates found by the sweep become wave-wide work items
@@ -607,6 +608,15 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                     const uint32_t j = (uint32_t)__builtin_clz(wm);
                                     wm ^= 0x80000000u >> j;
                                     *wp++ = (entry_t)(ebase + j);
+                                    // further records of the same word in the same trip: fewer trips, i.e. fewer taken branches
+#pragma unroll
+                                    for (int more = 0; more < kUnpackMore; more++) {
+                                        if (wm != 0u) {
+                                            const uint32_t j2 = (uint32_t)__builtin_clz(wm);
+                                            wm ^= 0x80000000u >> j2;
+                                            *wp++ = (entry_t)(ebase + j2);
+                                        }
+                                    }
                                 }
                             } else {
                                 entry_t* const wend = dst + n_new;
