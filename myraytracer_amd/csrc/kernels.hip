@@ -54,6 +54,42 @@ __device__ __forceinline__ float dot3(V3 a, V3 b) {
 }
 // WGSL normalize(e) = e / length(e)
 __device__ __forceinline__ V3 normalize3(V3 v) { return v / __builtin_sqrtf(dot3(v, v)); }
+// ---- IEEE division and square root without the operand scaling ------------------------------------------
+// `x / y` and sqrtf() compile to the correctly rounded expansions (v_div_scale x2, v_rcp, 7 fma-class operations,
+// v_div_fmas, v_div_fixup; a range test, v_sqrt, two residuals, two selects, a rescale and a class test).  The
+// functions below are those expansions WITHOUT the steps that only act on extreme operands, so wherever
+// v_div_scale_f32 would pass both operands through unscaled -- numerator and denominator finite and non-zero,
+// |n| >= 2^-102, the denominator and its reciprocal normal, -126 < exponent(n) - exponent(d) < 96 -- respectively
+// x >= 2^-96 finite, they execute the same operations on the same values and return the same bits as `/` and
+// sqrtf().  One refined reciprocal serves every numerator over the same denominator.  Each call site states why its
+// operands are in that range, or tests it and takes `/` and sqrtf() otherwise.
+struct Divisor { float d, r; };
+__device__ __forceinline__ Divisor divisor_of(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    Divisor D; D.d = d; D.r = r;
+    return D;
+}
+__device__ __forceinline__ float div_unscaled(float n, const Divisor D) {
+    float q = n * D.r;
+    float e = __builtin_fmaf(-D.d, q, n);
+    q = __builtin_fmaf(e, D.r, q);
+    e = __builtin_fmaf(-D.d, q, n);
+    return __builtin_fmaf(e, D.r, q);
+}
+// (x = +0 -> +0: the neighbour below is a NaN pattern, whose comparison is false, and the residual of the neighbour
+// above is +0, not > 0)
+__device__ __forceinline__ float sqrt_unscaled(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);                 // within 1 ulp: the answer is s or one of its neighbours
+    const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_down = __builtin_fmaf(-down, s, x), r_up = __builtin_fmaf(-up, s, x);
+    s = (r_down <= 0.0f) ? down : s;
+    s = (r_up > 0.0f) ? up : s;
+    return s;
+}
+constexpr float kDivMinNum = 0x1p-90f, kDivMinDen = 0x1p-30f;       // the tested call sites' bounds (upper bounds: 2^30, from
+                                                                    // the ABI's |coordinate| <= 1e7, api.cpp)
 // WGSL reflect(e1, e2) = e1 - 2*dot(e2, e1)*e2  (shader.wgsl:230)
 __device__ __forceinline__ V3 reflect3(V3 d, V3 n) {
     float k = 2.0f * dot3(n, d);
@@ -725,10 +761,15 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
                         const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sm.neg_r2)));
                         const float disc = __builtin_fmaf(bq, bq, -(ra * cq));
-                        const float d_sqrt = __builtin_sqrtf(disc);                   // :286
+                        // sqrt and the two divisions by `ra` without operand scaling: ra is within 1e-5 of 1 (`weird` rays
+                        // own no items), so scaling could only act on a numerator below 2^-102 or above 2^95 -- roots that
+                        // fail the range test below whatever their last bits -- and on disc < 2^-96, a d_sqrt below 2^-47
+                        // that changes -bq -+ d_sqrt only where that sum is below 2^-19 < t_min.
+                        const float d_sqrt = sqrt_unscaled(disc);                     // :286
                         const float t_min = 0.001f;                                   // :340
-                        const float t_near = (-bq - d_sqrt) / ra;                     // :290
-                        const float t_far = (-bq + d_sqrt) / ra;                      // :292
+                        const Divisor by_a = divisor_of(ra);
+                        const float t_near = div_unscaled(-bq - d_sqrt, by_a);        // :290
+                        const float t_far = div_unscaled(-bq + d_sqrt, by_a);         // :292
                         const bool ok_near = !(t_near < t_min) && t_near < 1.0e4f;
                         const bool ok_far = !(t_far < t_min) && t_far < 1.0e4f;
                         const float t = ok_near ? t_near : t_far;
@@ -888,7 +929,17 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 const V3 center = v3(sh0.x, sh0.y, sh0.z);
                 const float radius = sh0.w;
                 const V3 at = o + t_sup * d;                            // ray_normalized_at :103-105
-                normal = (at - center) / radius;
+                // (at - center) / radius, :299: one refined reciprocal for the three quotients where no lane's operands
+                // call for the scaling steps of `/` (see div_unscaled; a component that is 0 or below 2^-90, a radius
+                // below 2^-30: the literal expression for the wave)
+                const V3 rel = at - center;
+                const float rel_min = __builtin_fminf(__builtin_fminf(__builtin_fabsf(rel.x), __builtin_fabsf(rel.y)), __builtin_fabsf(rel.z));
+                if (__builtin_expect(__any(!(rel_min >= kDivMinNum && __builtin_fabsf(radius) >= kDivMinDen)), 0)) {
+                    normal = rel / radius;
+                } else {
+                    const Divisor by_r = divisor_of(radius);
+                    normal = v3(div_unscaled(rel.x, by_r), div_unscaled(rel.y, by_r), div_unscaled(rel.z, by_r));
+                }
                 const bool front_face = dot3(normal, d) <= 0.0f;
                 if (!front_face) normal = -normal;
                 // dyn_material_scatter, shader.wgsl:244-252
@@ -906,7 +957,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     const float r0 = front_face ? sh1.y : sh1.z;
                     float cos_t = dot3(-d, normal);
                     cos_t = (cos_t < 1.0f) ? cos_t : 1.0f;
-                    const float sin_t = __builtin_sqrtf(1.0f - cos_t * cos_t);
+                    // (1 - cos^2 for cos in [0, 1] is 0 or at least 2^-24: never in sqrtf()'s rescaled range)
+                    const float sin_t = sqrt_unscaled(1.0f - cos_t * cos_t);
                     const bool cannot_refract = (ri * sin_t) > 1.0f;
                     const float x1 = 1.0f - cos_t;
                     const float x2 = x1 * x1; const float x4 = x2 * x2; const float x5 = x4 * x1;
@@ -917,7 +969,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     } else {
                         const V3 perp = v3(ri * (d.x + cos_t * normal.x), ri * (d.y + cos_t * normal.y),
                                            ri * (d.z + cos_t * normal.z));
-                        const float k = -__builtin_sqrtf(__builtin_fabsf(1.0f - dot3(perp, perp)));
+                        const float k = -sqrt_unscaled(__builtin_fabsf(1.0f - dot3(perp, perp)));      // (0 or >= 2^-25, likewise)
                         ndir = v3(perp.x + k * normal.x, perp.y + k * normal.y, perp.z + k * normal.z);
                     }
                 } else {
@@ -943,7 +995,12 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             if (hit) {
                 bool scattered = true;
                 if (is_lambertian) {                                    // :203-216
-                    ndir = normal + normalize3(v3(bx, by, bz));             // unit_sphere :92-94
+                    // unit_sphere :92-94 = ball / sqrt(dot(ball, ball)).  A component of the ball point is +0 or at
+                    // least 2^-24 in magnitude (rng_pm1: a multiple of 2^-24 near 0), so the length is 0 or in [2^-24, 1.74]:
+                    // no operand in the range where `/` or sqrtf() rescale; +0 / len comes out +0 and the all-zero point
+                    // NaN, as written
+                    const Divisor by_len = divisor_of(sqrt_unscaled(__builtin_fmaf(bz, bz, __builtin_fmaf(by, by, bx * bx))));
+                    ndir = normal + v3(div_unscaled(bx, by_len), div_unscaled(by, by_len), div_unscaled(bz, by_len));
                     if (dot3(ndir, ndir) == 0.0f) ndir = normal;
                 } else if (is_metal) {                                  // :228-242
                     ndir = v3(refl.x + fuzz * bx, refl.y + fuzz * by, refl.z + fuzz * bz);
@@ -956,7 +1013,19 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             }
             // normalize() of the scattered direction (:354) and of the new sample's camera ray (:381), one code
             // path for the lanes of either kind
-            if (has_task && !task_done) d = normalize3(ndir);
+            if (has_task && !task_done) {
+                // d = ndir / sqrt(dot(ndir, ndir)); as for the normal: the literal expression if any lane has a component
+                // that is 0 or below 2^-90, or a squared length outside [2^-60, 2^60)
+                const float dd = dot3(ndir, ndir);
+                const float nd_min = __builtin_fminf(__builtin_fminf(__builtin_fabsf(ndir.x), __builtin_fabsf(ndir.y)), __builtin_fabsf(ndir.z));
+                const bool dd_ok = (__float_as_uint(dd) - 0x21800000u) < (0x5D800000u - 0x21800000u);      // bits of 2^-60, 2^60
+                if (__builtin_expect(__any(!(dd_ok && nd_min >= kDivMinNum)), 0)) {
+                    d = normalize3(ndir);
+                } else {
+                    const Divisor by_len = divisor_of(sqrt_unscaled(dd));
+                    d = v3(div_unscaled(ndir.x, by_len), div_unscaled(ndir.y, by_len), div_unscaled(ndir.z, by_len));
+                }
+            }
         }
         MRT_STAMP(0);
         if (COUNT) started += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(start_sample));
