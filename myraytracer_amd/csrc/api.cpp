@@ -805,6 +805,13 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
         // Selected where that stays below about a tenth of the typical R^2 (mrt_redraw checks the camera's
         // own distance the same way) and there are enough records to fill most of a 32-record tile.
         c->mfma_r2_ref = med_r2;
+        c->mfma_reach = 0.0;
+        for (int64_t i = 0; i < n; i++) {
+            const float* ctr = vec4 + 4 * (w->spheres.center_base_idx + i);
+            double d2 = 0.0;
+            for (int k = 0; k < 3; k++) { const double d = (double)ctr[k] - (double)c->mfma_origin[k]; d2 += d * d; }
+            c->mfma_reach = std::max(c->mfma_reach, std::sqrt(d2) + std::fabs((double)f32[w->spheres.radius_base_idx + i]));
+        }
         c->mfma_scene_ok = n_real >= 24 && med_r2 > 0.0 && kMfmaSlack * 2.0 * max_c2 <= 0.1 * med_r2;
     }
     HIP_TRY(c, upload((void**)&c->d_member_index, hier.member_index.data(), hier.member_index.size() * sizeof(uint32_t)));
@@ -944,6 +951,30 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     {
         p.use_mfma = use_matrix_core_sweep(c) ? 1u : 0u;
         for (int k = 0; k < 3; k++) p.mfma_origin[k] = c->mfma_origin[k];
+        // The sweep squares K oc.ds through an instruction that saturates at 1 (kernels.hip, mfma_sweep_tile), K a power of
+        // two: rays start on the camera's lens or on a sphere, i.e. within `all` of mfma_origin; the sweep admits origins up
+        // to 4 x that (others take the literal loop), records lie within `all`, |ds| < 1.001: |K oc.ds| < 5.01 all K <= 1/2.
+        double cam_d2 = 0.0, lens = 0.0;
+        for (int k = 0; k < 3; k++) {
+            const double d = (c->cam_raw.mode ? (double)c->cam_raw.origin[k] : 0.0) - (double)c->mfma_origin[k];
+            cam_d2 += d * d;
+        }
+        if (c->cam_raw.mode) {
+            double u2 = 0.0, v2 = 0.0;
+            for (int k = 0; k < 3; k++) { u2 += (double)c->cam_raw.ru[k] * c->cam_raw.ru[k]; v2 += (double)c->cam_raw.rv[k] * c->cam_raw.rv[k]; }
+            lens = std::sqrt(u2) + std::sqrt(v2);
+        }
+        double all = std::max(c->mfma_reach, std::sqrt(cam_d2) + lens);
+        if (!(all > 1e-30)) all = 1.0;
+        int e = 0;
+        (void)std::frexp(5.01 * all, &e);                       // 5.01 all < 2^e
+        const double K = std::ldexp(1.0, -(e + 1)), K2 = K * K;
+        p.mfma_scale[0] = (float)((double)mrt::kBoundStretch * K);
+        p.mfma_scale[1] = (float)(2.0 * K2);
+        p.mfma_scale[2] = (float)(-(1.0 - kMfmaSlack) * K2);
+        p.mfma_scale[3] = (float)(16.0 * all * all);
+        const uint32_t nk2 = (uint32_t)bf16_rne((float)-K2);    // a power of two: exact
+        p.mfma_neg_k2_pair = nk2 | (nk2 << 16);
     }
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
     p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records

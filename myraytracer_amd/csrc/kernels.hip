@@ -200,15 +200,19 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 // i.e. two [32 records] x [32 rays] GEMMs per tile.  The f32 MFMA runs on the vector FMA units (measured:
 // no overlap with VALU work), so the GEMMs run in bf16 on the matrix cores proper, with every f32 factor
 // split into bf16 pieces x = hi + lo (+ mid) and the cross products laid out along K = 16:
-//     k  0..2   C_hi (x,y,z)     . v_hi        v = ds for the first GEMM, -2 o for the second
+//     k  0..2   C_hi (x,y,z)     . v_hi        v = K ds for the first GEMM, 2 K^2 o for the second
 //     k  3..5   C_hi             . v_lo
 //     k  6..8   C_lo             . v_hi
-//     k  9..11  (1, 1, 1)        . (-o.ds | o.o (minus its slack)), each as hi, mid, lo
-//     k 12..14  Ck (hi, mid, lo) . (0, 0, 0 | 1, 1, 1)                 Ck = C.C - R^2 (minus its slack)
-// so ONE A operand per tile serves both; the first GEMM's result, squared and negated, is the C input of the
-// second, which therefore delivers U + o.o - (oc.ds)^2 = -S: one multiply and one alignbit per (ray, record).  What the split drops (C_lo v_lo and the remainders: 3 x 2^-18 of
+//     k  9..11  (1, 1, 1)        . (-K o.ds | -K^2 o.o (minus its slack)), each as hi, mid, lo
+//     k 12..14  Ck (hi, mid, lo) . (0, 0, 0 | -K^2 x (1, 1, 1))       Ck = C.C - R^2 (minus its slack)
+// so ONE A operand per tile serves both; the first GEMM's result g = -K oc.ds, squared where it is positive (the
+// record's centre ahead of the origin), is the C input of the second, which therefore delivers
+// K^2 (max(-oc.ds, 0)^2 - U - o.o) -- K^2 S for a centre ahead, K^2 (R^2 - |oc|^2) otherwise, which drops the bounds
+// that lie entirely behind the origin: one multiply and one alignbit per (ray, record).  K, a power of two chosen by
+// the host so that |g| <= 1/2 (KParams::mfma_scale), only makes the multiply's clamp to [0, 1] act as max(g, 0)^2; a
+// power of two changes no rounding.  What the split drops (C_lo v_lo and the remainders: 3 x 2^-18 of
 // every product) and the f32 accumulation err by at most 2.5e-5 o.o + 5e-5 C.C in S; the
-// test gives away 2^-13 = 1.2e-4 of o.o + C.C + R^2: o.o is scaled by kMfmaRaySlack here and the host
+// test gives away 2^-13 = 1.2e-4 of o.o + C.C + R^2: o.o is scaled by 1 - 2^-13 (in mfma_scale[2]) and the host
 // lowers Ck by 2^-13 (C.C + R^2) (api.cpp, build_top_mfma).  o and C are taken relative to the centre of the
 // records' bounding box (P.mfma_origin; the rounding of o - origin is relative to the difference), so the
 // slack does not depend on where the scene sits, only on its extent against R: the host selects this
@@ -221,7 +225,6 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 // order, so r[0] / r[1] are the masks of chunks 2t / 2t+1.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr float kMfmaRaySlack = 1.0f - 0x1p-13f;
 struct MfmaRay { u32x4 bp[2], bu[2]; };
 __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {          // two round-to-nearest conversions
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -234,12 +237,11 @@ __device__ __forceinline__ void swap32(uint32_t a, uint32_t b, uint32_t& r0, uin
     r0 = r[0];
     r1 = r[1];
 }
-__device__ __forceinline__ void mfma_pack_ray(V3 v, float w0, float w1, float w2, bool ones, u32x4 out[2]) {
+__device__ __forceinline__ void mfma_pack_ray(V3 v, float w0, float w1, float w2, uint32_t y2, uint32_t y3, u32x4 out[2]) {
     const V3 h = v3(bf16_round(v.x), bf16_round(v.y), bf16_round(v.z));
     const V3 l = v3(v.x - h.x, v.y - h.y, v.z - h.z);           // exact; rounded to bf16 by the packing below
     const uint32_t x0 = pk_bf16(h.x, h.y), x1 = pk_bf16(h.z, l.x), x2 = pk_bf16(l.y, l.z);      // k 0..5, 6..7 = x0
     const uint32_t y0 = pk_bf16(h.z, w0), y1 = pk_bf16(w1, w2);                                   // k 8..11
-    const uint32_t y2 = ones ? 0x3F803F80u : 0u, y3 = ones ? 0x00003F80u : 0u;                     // k 12..15
     uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
     swap32(x0, y0, a0, b0);
     swap32(x1, y1, a1, b1);
@@ -248,14 +250,17 @@ __device__ __forceinline__ void mfma_pack_ray(V3 v, float w0, float w1, float w2
     out[0] = u32x4{a0, a1, a2, a3};
     out[1] = u32x4{b0, b1, b2, b3};
 }
-__device__ __forceinline__ MfmaRay mfma_ray_operands(V3 o, V3 ds) {
+// `dsk` = K x the stretched direction, o2 = o.o, s2k2 = 2 K^2, nsk2 = -(1 - 2^-13) K^2, nk2 = -K^2 as a bf16 pair, K the
+// power of two of KParams::mfma_scale: the first GEMM comes out as K (C.ds - o.ds) = -K oc.ds, the second as
+// -K^2 (U + o.o) with o.o lowered by its slack.  Scaling by a power of two changes no rounding.
+__device__ __forceinline__ MfmaRay mfma_ray_operands(V3 o, V3 dsk, float o2, float s2k2, float nsk2, uint32_t nk2) {
     MfmaRay m;
-    const float nk0 = -dot3(o, ds);
+    const float nk0 = -dot3(o, dsk);
     const float n0 = bf16_round(nk0), n1 = bf16_round(nk0 - n0), n2 = (nk0 - n0) - n1;    // hi + mid + lo, each difference exact
-    mfma_pack_ray(ds, n0, n1, n2, false, m.bp);
-    const float k1p = dot3(o, o) * kMfmaRaySlack;
+    mfma_pack_ray(dsk, n0, n1, n2, 0u, 0u, m.bp);
+    const float k1p = o2 * nsk2;
     const float q0 = bf16_round(k1p), q1 = bf16_round(k1p - q0), q2 = (k1p - q0) - q1;
-    mfma_pack_ray(v3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z), q0, q1, q2, true, m.bu);
+    mfma_pack_ray(v3(s2k2 * o.x, s2k2 * o.y, s2k2 * o.z), q0, q1, q2, nk2, nk2 & 0xFFFFu, m.bu);     // k 12..14: -K^2, k 15: 0
     return m;
 }
 // one tile of 32 records against the wave's 64 rays; `a` = this lane's 8 bf16 of the tile's A operand
@@ -267,11 +272,18 @@ __device__ __forceinline__ uint32_t mfma_sweep_tile(const u32x4 a, const MfmaRay
     uint32_t hb[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        // -(oc.ds)^2 becomes the C input of the second GEMM, which then delivers U + o.o - (oc.ds)^2 = -S in the
-        // same 16 registers (a true candidate has S > 0 by the margin of the slack, so the sign of -S decides)
+        // The first GEMM gives g = -K oc.ds: positive where the record's centre lies AHEAD of the origin.  Its square
+        // becomes the C input of the second GEMM -- but only where g > 0: x |x| clamped to [0, 1] (the output modifier
+        // of the same multiply; |g| <= 1/2 by the choice of K) is max(g, 0)^2 -- which then delivers
+        // K^2 (max(-oc.ds, 0)^2 - U - o.o) in the same 16 registers.  For a centre ahead that is K^2 S, the stretched
+        // discriminant, positive for a true candidate by the margin of the slack; for a centre not ahead it is
+        // -K^2 c, c = |oc|^2 - R^2 (inflated, minus the slack): positive only if the origin lies inside the bound.
+        // A bound with its centre not ahead and the origin outside lies entirely behind the origin -- no root of
+        // anything inside it is positive (see the node rounds) -- and is no candidate: candidate = sign bit clear.
+        // (A g that is not > 0 only through rounding has g^2 far below the slack.)
         f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m.bp[h]), zero, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = -(acc[i] * acc[i]);
+        for (int i = 0; i < 16; i++) acc[i] = __builtin_amdgcn_fmed3f(acc[i] * __builtin_fabsf(acc[i]), 0.0f, 1.0f);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, m.bu[h]), acc, 0, 0, 0);
         uint32_t bb = 0;
 #pragma unroll
@@ -279,7 +291,7 @@ __device__ __forceinline__ uint32_t mfma_sweep_tile(const u32x4 a, const MfmaRay
         hb[h] = bb;
     }
     const auto r = __builtin_amdgcn_permlane32_swap(hb[0], hb[1], false, false);
-    return (r[0] << 16) | (r[1] & 0xFFFFu);            // record i of the tile at bit 31 - i
+    return ~((r[0] << 16) | (r[1] & 0xFFFFu));         // record i of the tile at bit 31 - i
 }
 
 // Candidate masks: per wave kBlockChunks / 2 x 64 lanes of u32 (one sign mask per 32 records -- two chunks, one
@@ -525,9 +537,15 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             // together with its direction -- origins are the camera's (validated: finite, |v| <= 1e7) or a hit point
             // o + t d of a finite ray and t < 1e4, and a hit point that is not finite makes the normal, hence the
             // scattered direction, NaN in the same iteration.
-            const bool weird = !(a > 0.99999f && a < 1.00001f);
+            // (matrix-core sweep: so does an origin further from the scene than the sweep's scaling admits -- 4 x the
+            // distance of the camera or of the farthest sphere surface, api.cpp: no ray of a frame, but a caller's ray
+            // under mrt_debug_world_hit may be)
+            const V3 o_rel = MFMA ? v3(o.x - P.mfma_origin[0], o.y - P.mfma_origin[1], o.z - P.mfma_origin[2]) : o;
+            const float o_rel2 = MFMA ? dot3(o_rel, o_rel) : 0.0f;
+            const bool weird = !(a > 0.99999f && a < 1.00001f) || (MFMA && !(o_rel2 <= P.mfma_scale[3]));
             const bool usable = trace && !weird;
-            const V3 ds = v3(d.x * kBoundStretch, d.y * kBoundStretch, d.z * kBoundStretch);
+            const float stretch = MFMA ? P.mfma_scale[0] : kBoundStretch;
+            const V3 ds = v3(d.x * stretch, d.y * stretch, d.z * stretch);
             // every lane leaves its ray where whoever picks up one of its work items finds it
             rays[2u * lane + 0u] = make_float4(o.x, o.y, o.z, d.x);
             rays[2u * lane + 1u] = make_float4(d.y, d.z, __uint_as_float((uint32_t)kNoHitKey), __uint_as_float((uint32_t)(kNoHitKey >> 32)));
@@ -561,7 +579,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
             // MFMA variant of the sweep: per-ray operands of the two GEMMs, rays x records (see mfma_sweep_tile)
             MfmaRay mr;
-            if (MFMA) mr = mfma_ray_operands(v3(o.x - P.mfma_origin[0], o.y - P.mfma_origin[1], o.z - P.mfma_origin[2]), ds);
+            if (MFMA) mr = mfma_ray_operands(o_rel, ds, o_rel2, P.mfma_scale[1], P.mfma_scale[2], P.mfma_neg_k2_pair);
             for (uint32_t blk = 0; blk < n_padded; blk += kBlockChunks * kChunk) {
                 const uint32_t blk_end = (blk + kBlockChunks * kChunk < n_padded) ? blk + kBlockChunks * kChunk : n_padded;
                 uint32_t nz = 0;                                        // bit w: records 32 w .. 32 w + 31 of this block hold a candidate

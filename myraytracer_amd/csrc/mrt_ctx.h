@@ -29,6 +29,7 @@ struct mrt_ctx {
     bool mfma_scene_ok = false;            // the expanded test's extra slack is negligible for this scene
     double mfma_r2_ref = 0.0;              // median R^2 of the top level (camera check at launch)
     float mfma_origin[3] = {0.0f, 0.0f, 0.0f};   // the matrix-core sweep works in coordinates relative to this point
+    double mfma_reach = 0.0;                      // max over ALL spheres of |centre - mfma_origin| + |radius|: no hit point lies further out
     int sweep_mode = 0;                    // 0 automatic, 1 SGPR-fed VALU sweep, 2 matrix-core sweep (mrt_debug_set_sweep)
     float* d_shade = nullptr;              // 8 floats per sphere: centre, radius, material colour, fuzz | ior
     mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...

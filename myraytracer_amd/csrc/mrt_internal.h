@@ -51,6 +51,11 @@ struct KParams {
     const uint16_t* top_mfma;
     uint32_t use_mfma;
     float mfma_origin[3];       // the records of top_mfma are relative to this point (centre of their bounding box)
+    // The ray-side factors of the matrix-core sweep (api.cpp, fill_scene_params): with K a power of two such that
+    // |K oc.ds| <= 1/2 for every ray the sweep admits, {kBoundStretch K, 2 K^2, -(1 - 2^-13) K^2, the largest admitted
+    // |o - mfma_origin|^2}, and -K^2 as a pair of bf16 (kernels.hip, mfma_ray_operands)
+    float mfma_scale[4];
+    uint32_t mfma_neg_k2_pair;
     const SphereRec* nodes;
     const uint32_t* member_index;
     uint32_t levels, n_nodes, n_members, gen_cap;
