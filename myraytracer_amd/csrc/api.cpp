@@ -339,6 +339,7 @@ struct Hierarchy {
     uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
     uint32_t n_direct = 0, direct_first = 0;
     mrt::SphereRec direct[mrt::kMaxDirect] = {};
+    uint32_t direct_index[mrt::kMaxDirect] = {};
 };
 
 void build_hierarchy(const float* centers4, const float* radii, uint32_t n, float factor, uint32_t max_levels,
@@ -360,6 +361,7 @@ void build_hierarchy(const float* centers4, const float* radii, uint32_t n, floa
             rec = mrt::SphereRec{centers4[4 * idx], centers4[4 * idx + 1], centers4[4 * idx + 2], -(r * r)};
         }
         H.direct[j] = rec;
+        H.direct_index[j] = idx;
         if (!direct.empty()) { H.nodes.push_back(rec); H.member_index.push_back(idx); }
     }
     static_assert(mrt::kMaxDirect == mrt::kClusterK, "level 0 stays a multiple of kClusterK");
@@ -854,7 +856,7 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
     c->levels = hier.levels; c->n_nodes = (uint32_t)hier.nodes.size(); c->n_members = hier.n_members;
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) c->level_base[k] = hier.level_base[k];
     c->n_direct = hier.n_direct; c->direct_first = hier.direct_first;
-    for (uint32_t k = 0; k < mrt::kMaxDirect; k++) c->direct[k] = hier.direct[k];
+    for (uint32_t k = 0; k < mrt::kMaxDirect; k++) { c->direct[k] = hier.direct[k]; c->direct_index[k] = hier.direct_index[k]; }
     c->have_world = true;
     c->set_world_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return MRT_OK;
@@ -980,7 +982,7 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) p.level_base[k] = c->level_base[k];
     p.n_direct = c->n_direct; p.direct_first = c->direct_first;
-    for (uint32_t k = 0; k < mrt::kMaxDirect; k++) p.direct[k] = c->direct[k];
+    for (uint32_t k = 0; k < mrt::kMaxDirect; k++) { p.direct[k] = c->direct[k]; p.direct_index[k] = c->direct_index[k]; }
     p.cus = c->cus;
     p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.top_mfma = c->d_top_mfma; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.shade = c->d_shade; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
 }

@@ -546,36 +546,47 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             const bool usable = trace && !weird;
             const float stretch = MFMA ? P.mfma_scale[0] : kBoundStretch;
             const V3 ds = v3(d.x * stretch, d.y * stretch, d.z * stretch);
+            // The few spheres far larger than the rest (a ground sphere) are outside the hierarchy: every ray does
+            // sphere_hit (shader.wgsl:274-296) on them itself, record in SGPRs -- discriminant, and for lanes with
+            // disc >= 0 (and the sphere not entirely behind the origin: see the node rounds) the roots and range tests
+            // exactly as a root round would, sqrt and quotients by `a` in their unscaled forms for the same reason.
+            // Their closest root is what the lane's hit slot starts from: a ground sphere is a candidate for most rays,
+            // and as work items these were more than half of the root rounds' load.
+            unsigned long long key0 = kNoHitKey;
+            {
+                const KArgPtr C = cold_args();
+                const uint32_t n_direct = C->n_direct;
+                const Divisor by_a = divisor_of(a);
+                for (uint32_t j = 0; j < n_direct; j++) {
+                    const float cx = C->direct[j].cx, cy = C->direct[j].cy, cz = C->direct[j].cz, nr2 = C->direct[j].neg_r2;
+                    const uint32_t sidx = C->direct_index[j];
+                    const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
+                    const float bq = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));
+                    const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, nr2)));
+                    const float disc = __builtin_fmaf(bq, bq, -(a * cq));
+                    const bool cand = !(disc < 0.0f), ahead = (int32_t)(__float_as_uint(bq) | __float_as_uint(cq)) < 0;
+                    const bool hq = usable && cand && ahead;
+                    const float d_sqrt = sqrt_unscaled(disc);                     // :286
+                    const float t_min = 0.001f;                                   // :340
+                    const float t_near = div_unscaled(-bq - d_sqrt, by_a);        // :290
+                    const float t_far = div_unscaled(-bq + d_sqrt, by_a);         // :292
+                    const bool ok_near = !(t_near < t_min) && t_near < 1.0e4f;
+                    const bool ok_far = !(t_far < t_min) && t_far < 1.0e4f;
+                    const float t = ok_near ? t_near : t_far;
+                    const unsigned long long key = (hq && (ok_near || ok_far)) ? (((unsigned long long)__float_as_uint(t) << 32) | sidx) : kNoHitKey;
+                    key0 = key < key0 ? key : key0;
+                    if (DBG && hq) atomicOr(P.dbg_cand + (size_t)texel * P.dbg_words + (sidx >> 5), 1u << (sidx & 31u));
+                }
+                if (COUNT) mtests += (unsigned long long)n_direct * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(usable));
+            }
             // every lane leaves its ray where whoever picks up one of its work items finds it
             rays[2u * lane + 0u] = make_float4(o.x, o.y, o.z, d.x);
-            rays[2u * lane + 1u] = make_float4(d.y, d.z, __uint_as_float((uint32_t)kNoHitKey), __uint_as_float((uint32_t)(kNoHitKey >> 32)));
+            rays[2u * lane + 1u] = make_float4(d.y, d.z, __uint_as_float((uint32_t)key0), __uint_as_float((uint32_t)(key0 >> 32)));
             lds_order();
             // Conservative sweep + cooperative walk, in blocks of kBlockChunks x kChunk cluster records.
             // The records are wave-uniform: they are fetched with scalar loads, 8 records (two
             // s_load_dwordx16 = 32 SGPRs) per group, double-buffered: wait for group g, issue the
             // loads of group g+1, then run the 8 x 11 VALU ops of group g while they fly.
-            // The few spheres far larger than the rest (a ground sphere) are outside the hierarchy: every
-            // ray evaluates their discriminant (shader.wgsl:274-282) itself, record in SGPRs, and queues
-            // the ones with disc >= 0 for the root rounds like any other member.
-            uint32_t n_hits0 = 0;
-            {
-                const KArgPtr C = cold_args();
-                const uint32_t n_direct = C->n_direct;
-                for (uint32_t j = 0; j < n_direct; j++) {
-                    const float cx = C->direct[j].cx, cy = C->direct[j].cy, cz = C->direct[j].cz, nr2 = C->direct[j].neg_r2;
-                    const float ocx = o.x - cx, ocy = o.y - cy, ocz = o.z - cz;
-                    const float bq = __builtin_fmaf(ocz, d.z, __builtin_fmaf(ocy, d.y, ocx * d.x));
-                    const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, nr2)));
-                    const float disc = __builtin_fmaf(bq, bq, -(a * cq));
-                    // (not queued when the sphere is entirely behind the origin: see the node rounds)
-                    const bool cand = !(disc < 0.0f), ahead = (int32_t)(__float_as_uint(bq) | __float_as_uint(cq)) < 0;
-                    const bool hq = usable && cand && ahead;
-                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(hq);
-                    if (hq) queues[n_hits0 + rank_in(mk)] = (entry_t)((lane << kIdBits) | (C->direct_first + j));
-                    n_hits0 += (uint32_t)__popcll(mk);
-                }
-                if (COUNT) mtests += (unsigned long long)n_direct * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(usable));
-            }
             uint32_t bits = 0;      // running sign history; its low 16 (or 8) bits are the current chunk
             // MFMA variant of the sweep: per-ray operands of the two GEMMs, rays x records (see mfma_sweep_tile)
             MfmaRay mr;
@@ -629,8 +640,6 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 uint32_t qn[kLvMax + 1];
 #pragma unroll
                 for (int lv = 0; lv <= kLvMax; lv++) qn[lv] = 0u;
-                qn[0] = n_hits0;            // (at most kMaxDirect x 64 <= the queue's capacity; root rounds come first)
-                n_hits0 = 0;
                 for (;;) {
                     // a full round at the deepest level that has one; else refill the top queue; else
                     // a partial round at the highest level that has anything

@@ -40,6 +40,7 @@ struct mrt_ctx {
     uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
     uint32_t n_direct = 0, direct_first = 0;
     mrt::SphereRec direct[mrt::kMaxDirect] = {};
+    uint32_t direct_index[mrt::kMaxDirect] = {};
     float* d_vec4 = nullptr;
     float* d_f32 = nullptr;
     int32_t* d_i32 = nullptr;

@@ -65,6 +65,7 @@ struct KParams {
     // They are the members direct_first .. direct_first + n_direct - 1 of level 0.
     uint32_t n_direct, direct_first;
     SphereRec direct[kMaxDirect];
+    uint32_t direct_index[kMaxDirect];      // their indices in the reference's sphere order
     const float* vec4_data;     // r_vec4_f32_data (shader.wgsl:189-190), 4 floats per texel
     const float* f32_data;      // r_f32_data
     const int32_t* i32_data;    // r_i32_data
