@@ -151,3 +151,30 @@ def test_stress_scene_10k(mrt, oracle):
     tgt = rng.uniform(sc["center"][:-1].min(0), sc["center"][:-1].max(0), (1500, 3))
     rays = np.concatenate([rays, np.concatenate([cam_o, _normalize(oracle, tgt - cam_o)], 1)], 0)
     _check(mrt, oracle, sc, rays, what="stress 10k")
+
+
+def test_origins_beyond_the_sweeps_scaling_take_the_literal_loop(mrt, oracle):
+    """The matrix-core sweep scales its operands so that K oc.ds stays below 1/2 for origins within 4 x the scene's reach
+    (api.cpp, fill_scene_params); a caller's ray from farther away must still find the reference's winner (it takes the
+    index-ordered loop over all spheres, which records no candidates)."""
+    rng = np.random.default_rng(5)
+    sc = _random_scene(mrt, rng, 300, ground=False)
+    c = sc["center"].astype(np.float64)
+    k = rng.integers(0, len(sc), 3000)
+    u = rng.normal(size=(3000, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    dist = rng.choice([3.0, 40.0, 200.0, 5000.0], 3000)[:, None]          # x the scene's half extent (~8): inside and far outside
+    o = c[k] + u * dist * 8.0
+    d = c[k] + rng.normal(size=(3000, 3)) * 0.2 - o
+    rays = np.concatenate([o, d / np.linalg.norm(d, axis=1, keepdims=True)], 1).astype(np.float32)
+    a2 = (rays[:, 3:].astype(np.float64) ** 2).sum(1)
+    rays = rays[np.abs(a2 - 1.0) < 5e-6]
+    packed = oracle.pack_world(to_oracle_spheres(oracle, sc))
+    ref_hit, ref_t, _, _ = oracle.world_hit_batch(packed, rays)
+    with mrt.State(mrt.Args(16, 16), seed=1) as st:
+        st.set_world(sc)
+        st.debug_set_sweep(2)
+        hit, t, _ = st.debug_world_hit(rays, len(sc))
+    assert (ref_hit >= 0).sum() > 500
+    assert np.array_equal(hit, ref_hit)
+    assert np.array_equal(t.view(np.uint32)[hit >= 0], ref_t.view(np.uint32)[hit >= 0])
