@@ -324,6 +324,7 @@ constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 
 constexpr uint32_t kQueueCap = 320;       // < 64 left over + 4 x 64 pushed by one round (top queue: P.gen_cap)
 constexpr unsigned long long kNoHitKey = 0x461C4000FFFFFFFFull;   // (bits(1e4f) << 32) | -1
 
+template <int N> struct IC { static constexpr int value = N; };
 template <bool SMALL> struct Ent;
 template <> struct Ent<true>  { typedef uint16_t type; static constexpr uint32_t id_bits = 10u; };
 template <> struct Ent<false> { typedef uint32_t type; static constexpr uint32_t id_bits = 26u; };
@@ -703,31 +704,33 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         for (int lv = kLvMax; lv >= 0; lv--) if (k < 0 && qn[lv] != 0u) k = lv;
                         if (k < 0) break;
                     }
-                    uint32_t n = 0;
-#pragma unroll
-                    for (int lv = 0; lv <= kLvMax; lv++) n = (k == lv) ? qn[lv] : n;
+                    // One round at level K, K a compile-time constant in each copy: the queue counters are plain registers and
+                    // the level-dependent choices (stretch, `a`, the children's base) fold away.  (With the level a run-time
+                    // value every access was a chain of selects over the levels -- half the instructions of a large scene's
+                    // round.)
+                    auto round_at = [&](auto KC) {
+                    constexpr int K = decltype(KC)::value;
+                    const uint32_t n = qn[K];
                     const uint32_t take = n < 64u ? n : 64u, start = n - take;
                     const bool act = lane < take;
-                    const entry_t* const src = queues + (uint32_t)k * kQueueCap;
+                    const entry_t* const src = queues + (uint32_t)K * kQueueCap;
                     const uint32_t it = src[act ? start + lane : 0u];
                     const uint32_t owner = it >> kIdBits, node = it & ((1u << kIdBits) - 1u);
                     const float4 r0 = rays[2u * owner];
                     const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
                     const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r0.w, r1.x, r1.y);
                     const float ra = dot3(rd, rd);                      // the owner's `a`, same expression
-                    if (k != 0) {
+                    if constexpr (K != 0) {
                         // node round, 4 children per item.  k == 1: the reference's discriminant (shader.wgsl:274-282)
                         // for the cluster's members; members with disc >= 0 become (owner, member) items.
                         // k >= 2: the sweep's conservative test on the child bounds (the same expression with
                         // the direction stretched and a = 1, bit for bit test1()); passing children become items.
                         // (Round 1 rotated the four reads by node/4 to spread one read's 64 lanes over all LDS banks; the 8
                         // VALU of address arithmetic per round cost more than the bank conflicts they avoided: round 2.)
-                        const bool inner = kLvMax >= 2 && k >= 2;
+                        constexpr bool inner = K >= 2;
                         const float sc = inner ? kBoundStretch : 1.0f, ra_eff = inner ? 1.0f : ra;
                         const V3 re = v3(rd.x * sc, rd.y * sc, rd.z * sc);
-                        uint32_t cbase = 0;                 // first record of the children's level
-#pragma unroll
-                        for (int lv = 1; lv < kLvMax; lv++) cbase = (k - 1 == lv) ? P.level_base[lv] : cbase;
+                        const uint32_t cbase = K >= 2 ? P.level_base[K >= 2 ? K - 1 : 0] : 0u;      // first record of the children's level
                         const SphereRec* const ch = nodes + cbase + 4u * node;
                         bool h[4];
                         unsigned long long hm[4];
@@ -751,10 +754,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                 hm[q] = __builtin_amdgcn_ballot_w64(h[q]);
                             }
                         }
-                        uint32_t dn = 0;
-#pragma unroll
-                        for (int lv = 0; lv < kLvMax; lv++) dn = (k - 1 == lv) ? qn[lv] : dn;
-                        entry_t* const dst = queues + (uint32_t)(k - 1) * kQueueCap + dn;
+                        const uint32_t dn = qn[K - 1];
+                        entry_t* const dst = queues + (uint32_t)(K - 1) * kQueueCap + dn;
                         const uint32_t e0 = (owner << kIdBits) | (4u * node);
                         uint32_t pushed = 0;
                         const unsigned long long act_mask = take >= 64u ? ~0ull : ((1ull << take) - 1ull);
@@ -764,12 +765,9 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                             if (h[q] && act) dst[pushed + rank_in(mk)] = (entry_t)(e0 + (uint32_t)q);
                             pushed += (uint32_t)__popcll(mk);
                         }
-#pragma unroll
-                        for (int lv = 0; lv <= kLvMax; lv++) {
-                            if (k == lv) qn[lv] = start;
-                            if (k - 1 == lv) qn[lv] += pushed;
-                        }
-                        if (COUNT && k == 1) mtests += kClusterK * take;
+                        qn[K] = start;
+                        qn[K - 1] += pushed;
+                        if (COUNT && K == 1) mtests += kClusterK * take;
 #ifdef MRT_STAMPS
                         rounds_a_++; items_a_ += take;
 #endif
@@ -814,6 +812,16 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
 #endif
                         lds_order();
                         MRT_STAMP(3);
+                    }
+                    };
+                    if (k == 0) round_at(IC<0>{});
+                    else if (kLvMax == 1 || k == 1) round_at(IC<1>{});
+                    else if constexpr (kLvMax >= 2) {
+                        if (k == 2) round_at(IC<2>{});
+                        else if constexpr (kLvMax >= 3) {
+                            if (k == 3) round_at(IC<3>{});
+                            else if constexpr (kLvMax >= 4) round_at(IC<4>{});
+                        }
                     }
                 }
             }

@@ -16,6 +16,8 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 
     if os.environ.get("MRT_HIER"):        # "max_levels,top_target"
         h_ = [int(x) for x in os.environ["MRT_HIER"].split(",")]
         assert _lib.load().mrt_debug_set_hierarchy(st._ctx, h_[0], h_[1]) == 0
+    if os.environ.get("MRT_WAVES_PER_CU"):   # persistent waves per CU (0 = what the kernel's registers / LDS admit)
+        assert _lib.load().mrt_debug_set_schedule(st._ctx, 1, int(os.environ["MRT_WAVES_PER_CU"])) == 0
     if os.environ.get("MRT_NOBATCH"):     # mrt_render without sharing launches among frames
         assert _lib.load().mrt_debug_set_frame_batching(st._ctx, 0) == 0
     if os.environ.get("MRT_CLUSTER"):
