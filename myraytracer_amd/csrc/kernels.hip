@@ -9,10 +9,11 @@
 //     live lane, whichever sample / bounce that lane is on;
 //   * `world_hit` (shader.wgsl:314-329) is split into (1) a branch-free, conservative sweep over
 //     the top level of a 4-ary hierarchy of bounding spheres (clusters of <= 4 neighbouring spheres,
-//     and for large scenes bounds of bounds) -- the records are wave-uniform, so they are fetched by
-//     scalar loads into SGPRs (no LDS, no VGPRs, no per-lane bandwidth); each costs 10 fp32 VALU ops +
-//     1 v_alignbit that shifts the sign of the test into a per-lane 16-record bitmask kept in LDS --
-//     and (2) a COOPERATIVE walk: the candidates of all 64 rays become work items (owner lane, node)
+//     and for large scenes bounds of bounds) -- where the scene admits it as two bf16-split GEMMs per 32
+//     records on the matrix cores, which also drop the bounds that lie behind the ray's origin (1 multiply
+//     + 1 v_alignbit per ray and record on the VALU); otherwise from wave-uniform records fetched by scalar
+//     loads into SGPRs (10 fp32 VALU ops + 1 v_alignbit); either way the signs land in per-lane bitmasks
+//     kept in LDS -- and (2) a COOPERATIVE walk: the candidates of all 64 rays become work items (owner lane, node)
 //     in small LDS queues and every round 64 lanes take 64 items, whoever owns them: node rounds
 //     evaluate the reference's discriminant for the 4 members of a cluster (or the conservative test
 //     for the 4 children of an inner node), root rounds its sqrt / divide / range tests
@@ -28,7 +29,8 @@
 //     RGBA32F store per pixel per frame, whole 128-byte lines per 8x8 tile.
 //
 // Arithmetic follows the "MRT-F32" rules: fma only where written, no
-// contraction (-ffp-contract=off), correctly rounded sqrt and divide (hipcc default).
+// contraction (-ffp-contract=off), correctly rounded sqrt and divide (hipcc's default expansions, or those
+// expansions minus the operand-scaling steps where the operands cannot need them: div_unscaled, sqrt_unscaled).
 // The CPU oracle under oracle/ implements the same rules independently; tests require
 // bit-identical framebuffers.
 
