@@ -283,6 +283,11 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
                               float* top_out, size_t top_cap, float* nodes_out, size_t nodes_cap,
                               uint32_t* member_index_out, size_t member_cap, uint16_t* mfma_out, size_t mfma_cap,
                               float mfma_origin_out[3], uint32_t info[10]);
+/* Host-side diagnostic, no GPU needed: the ray-side factors of the matrix-core sweep for a scene and camera that keep every
+ * ray origin and every bound within `reach` of the sweep's origin: scale_out[4] = {stretch K, 2 K^2,
+ * -(1 - 2^-13) K^2, (4 reach)^2} with K the power of two for which |K oc.ds| <= 1/2 for every admitted ray, and
+ * *neg_k2_bf16_pair_out = -K^2 as two bf16.  What mrt_redraw passes to the kernel (tests/test_host_logic.py). */
+int mrt_debug_mfma_scale(double reach, float scale_out[4], uint32_t* neg_k2_bf16_pair_out);
 /* Diagnostic: ONE world_hit (shader.wgsl:314-329, range [0.001, 1e4)) for each of n caller-supplied rays -- rays[6 i ..] =
  * origin xyz, direction xyz; directions of unit length to 1e-5, as every ray of the render loop is -- through the very sweep +
  * walk the render kernel runs (the same kernel, instantiated to take its rays from this array), with the current scene,

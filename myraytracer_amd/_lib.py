@@ -19,7 +19,7 @@ EXPORTS = [
     "mrt_reset", "mrt_get_locals", "mrt_set_rng_shuffle", "mrt_set_samples_per_frame", "mrt_set_rng_mode",
     "mrt_frames_done", "mrt_frame_weight", "mrt_frame_shuffle", "mrt_pixel_seed", "mrt_shard_info",
     "mrt_framebuffer_device_ptr", "mrt_read_framebuffer", "mrt_read_counters", "mrt_last_kernel_ms",
-    "mrt_kernel_ms_history", "mrt_debug_read_counters", "mrt_debug_wave_log", "mrt_debug_set_tile_sort", "mrt_debug_set_cluster_factor", "mrt_debug_set_hierarchy", "mrt_debug_set_sweep", "mrt_debug_sweep_variant", "mrt_debug_build_hierarchy", "mrt_debug_read_pixel_costs", "mrt_debug_set_schedule",
+    "mrt_kernel_ms_history", "mrt_debug_read_counters", "mrt_debug_wave_log", "mrt_debug_set_tile_sort", "mrt_debug_set_cluster_factor", "mrt_debug_set_hierarchy", "mrt_debug_set_sweep", "mrt_debug_sweep_variant", "mrt_debug_build_hierarchy", "mrt_debug_read_pixel_costs", "mrt_debug_set_schedule", "mrt_debug_mfma_scale",
     "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_scene_default", "mrt_scene_cover",
     "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
     "mrt_srgb8", "mrt_write_png", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
@@ -141,6 +141,7 @@ def load():
         "mrt_debug_build_hierarchy": (i32, [vp, sz, u32, u32, vp, sz, vp, sz, vp, sz, vp, sz, vp, vp]),
         "mrt_debug_read_pixel_costs": (i32, [vp, vp, sz]),
         "mrt_debug_set_schedule": (i32, [vp, u32, i32]),
+        "mrt_debug_mfma_scale": (i32, [C.c_double, vp, vp]),
         "mrt_last_error": (C.c_char_p, [vp]),
         "mrt_status_string": (C.c_char_p, [i32]),
         "mrt_abi_version": (i32, []),

@@ -943,6 +943,20 @@ int mrt_read_seeds(mrt_ctx* c, uint32_t* out, size_t cap) {
 
 }  // extern "C"
 
+// KParams::mfma_scale / mfma_neg_k2_pair for rays and records within `all` of the sweep's origin (mrt_debug_mfma_scale)
+static void mfma_scales(double all, float scale[4], uint32_t* neg_k2_pair) {
+    if (!(all > 1e-30)) all = 1.0;
+    int e = 0;
+    (void)std::frexp(5.01 * all, &e);                       // 5.01 all < 2^e
+    const double K = std::ldexp(1.0, -(e + 1)), K2 = K * K;
+    scale[0] = (float)((double)mrt::kBoundStretch * K);
+    scale[1] = (float)(2.0 * K2);
+    scale[2] = (float)(-(1.0 - kMfmaSlack) * K2);
+    scale[3] = (float)(16.0 * all * all);
+    const uint32_t nk2 = (uint32_t)bf16_rne((float)-K2);    // a power of two: exact
+    *neg_k2_pair = nk2 | (nk2 << 16);
+}
+
 // the scene / hierarchy / sweep-variant part of the kernel arguments (everything that does not depend on the frame)
 static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     p.world = c->world;
@@ -966,17 +980,7 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
             for (int k = 0; k < 3; k++) { u2 += (double)c->cam_raw.ru[k] * c->cam_raw.ru[k]; v2 += (double)c->cam_raw.rv[k] * c->cam_raw.rv[k]; }
             lens = std::sqrt(u2) + std::sqrt(v2);
         }
-        double all = std::max(c->mfma_reach, std::sqrt(cam_d2) + lens);
-        if (!(all > 1e-30)) all = 1.0;
-        int e = 0;
-        (void)std::frexp(5.01 * all, &e);                       // 5.01 all < 2^e
-        const double K = std::ldexp(1.0, -(e + 1)), K2 = K * K;
-        p.mfma_scale[0] = (float)((double)mrt::kBoundStretch * K);
-        p.mfma_scale[1] = (float)(2.0 * K2);
-        p.mfma_scale[2] = (float)(-(1.0 - kMfmaSlack) * K2);
-        p.mfma_scale[3] = (float)(16.0 * all * all);
-        const uint32_t nk2 = (uint32_t)bf16_rne((float)-K2);    // a power of two: exact
-        p.mfma_neg_k2_pair = nk2 | (nk2 << 16);
+        mfma_scales(std::max(c->mfma_reach, std::sqrt(cam_d2) + lens), p.mfma_scale, &p.mfma_neg_k2_pair);
     }
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
     p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records
@@ -1254,6 +1258,12 @@ int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_ou
 int mrt_debug_sweep_variant(mrt_ctx* c) {
     if (!c || !c->have_world) return 0;
     return use_matrix_core_sweep(c) ? 2 : 1;
+}
+
+int mrt_debug_mfma_scale(double reach, float scale_out[4], uint32_t* neg_k2_bf16_pair_out) {
+    if (!scale_out || !neg_k2_bf16_pair_out || !(reach >= 0.0) || !std::isfinite(reach)) return MRT_ERR_INVALID_ARG;
+    mfma_scales(reach, scale_out, neg_k2_bf16_pair_out);
+    return MRT_OK;
 }
 
 int mrt_debug_set_hierarchy(mrt_ctx* c, uint32_t max_levels, uint32_t top_target) {

@@ -222,3 +222,31 @@ def test_scene_file_errors_name_the_line(mrt, tmp_path):
     sc, cam = mrt.load_scene(str(ok))
     assert len(sc) == 2 and cam is not None and cam.mode == 0
     assert sc[1]["material_ty"] == mrt.METAL and sc[1]["param"] == 1.0 and tuple(sc[0]["center"]) == (0.0, -100.5, -1.0)
+
+
+def test_matrix_core_sweep_scale_keeps_the_clamp_from_saturating(mrt):
+    """api.cpp mfma_scales: the sweep squares g = K oc.ds with an instruction that clamps to [0, 1] (kernels.hip,
+    mfma_sweep_tile), so K must be a power of two (no rounding changes) with |g| <= 1/2 for every admitted ray: origins up
+    to 4 x reach, records within reach, |ds| < 1.001."""
+    import ctypes as C
+    import struct
+    from myraytracer_amd import _lib
+    L = _lib.load()
+    for reach in [1e-4, 0.03, 0.5, 1.0, 13.7, 1000.0, 1.73e7, 6.0e7]:
+        sc = (C.c_float * 4)()
+        pair = C.c_uint32()
+        assert L.mrt_debug_mfma_scale(reach, sc, C.byref(pair)) == 0
+        K2 = sc[1] / 2.0
+        K = K2 ** 0.5
+        m, e = np.frexp(K)
+        assert m == 0.5, "K is a power of two"
+        assert 5.01 * reach * K <= 0.5 and 5.01 * reach * K > 0.0624          # |g| <= 1/2, and no more than 3 bits given away
+        assert sc[0] == np.float32(np.float32(1.0001) * np.float32(K))         # kBoundStretch x K, exact scaling
+        assert sc[2] == np.float32(-(1.0 - 2.0 ** -13) * K2)
+        assert sc[3] == np.float32(16.0 * reach * reach)
+        lo, hi = pair.value & 0xFFFF, pair.value >> 16
+        assert lo == hi and struct.unpack("<f", struct.pack("<I", lo << 16))[0] == -K2   # -K^2 as bf16, exact
+    sc = (C.c_float * 4)()
+    pair = C.c_uint32()
+    assert L.mrt_debug_mfma_scale(float("nan"), sc, C.byref(pair)) != 0
+    assert L.mrt_debug_mfma_scale(0.0, sc, C.byref(pair)) == 0 and sc[1] > 0      # an empty scene: any K
