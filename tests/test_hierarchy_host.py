@@ -119,3 +119,88 @@ def test_matrix_core_operand_restates_the_top_level_with_its_slack(mrt):
                 R2 = -float(rec[3])
                 assert ck3.sum() <= c2 - R2 - SLACK * (c2 + R2) + 1e-9 * (c2 + R2), (name, t, m)
                 assert ck3.sum() >= c2 - R2 - 1.01 * SLACK * (c2 + R2) - 1e-5 * (np.sqrt(c2 * R2) + R2), (name, t, m)
+
+
+def bf16_round(x):
+    """round-to-nearest-even of float32 values to bf16, returned as float32 (kernels.hip bf16_round)"""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def split3(x):
+    x = np.asarray(x, np.float32)
+    a = bf16_round(x)
+    b = bf16_round(x - a)
+    return a, b, bf16_round((x - a) - b)
+
+
+def test_matrix_core_sweep_algebra_is_conservative_and_drops_only_what_lies_behind(mrt):
+    """The sweep's two GEMMs (kernels.hip mfma_ray_operands / mfma_sweep_tile) restated in numpy from the very A operand the
+    host uploads and the scale factors it passes (mrt_debug_mfma_scale): g = A.B1 = -K oc.ds, C = clamp(g |g|) = max(g, 0)^2,
+    result = A.B2 + C = K^2 (max(-oc.ds, 0)^2 - U - o.o), candidate = result not < 0.  Products of bf16 pieces are exact in
+    float64 here (the hardware accumulates in f32; that error is what the 2^-13 slack is for).  Every top-level bound whose
+    ENCLOSED sphere (radius / 1.015) the ray's forward half-line touches must be a candidate; every bound that is dropped
+    although the full line touches it must lie entirely behind the origin; and |g| must stay below 1/2."""
+    L = _lib.load()
+    rng = np.random.default_rng(9)
+    for name, sc in scenes(mrt):
+        if len(sc) < 30:
+            continue
+        h = build(mrt, sc)
+        top, org = h["top"].astype(np.float64), h["origin"]
+        A = bf16(h["mfma"].reshape(-1, 2, 32, 8))                              # [tile, half, row, 8] -> values
+        A = np.concatenate([A[:, 0], A[:, 1]], axis=-1)                        # [tile, row, 16]
+        order = [32 * t + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3) for t in range(len(top) // 32) for m in range(32)]
+        A = A.reshape(-1, 16)
+        rec = top[order]
+        real = np.isfinite(rec[:, 3])
+        c_all = np.asarray(sc["center"], np.float64).reshape(-1, 3)
+        r_all = np.abs(np.asarray(sc["radius"], np.float64))
+        reach = float((np.linalg.norm(c_all - org, axis=1) + r_all).max())
+        scale = (C.c_float * 4)()
+        pair = C.c_uint32()
+        assert L.mrt_debug_mfma_scale(reach, scale, C.byref(pair)) == 0
+        s_ds, s_2k2, s_nk2slack, o2_max = (np.float32(v) for v in scale)
+        neg_k2 = np.float32(np.array([(pair.value & 0xFFFF) << 16], np.uint32).view(np.float32)[0])
+        # rays: origins on and around the spheres (within the admitted 4 x reach), unit directions
+        n = 400
+        k = rng.integers(0, len(sc), n)
+        u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+        o = c_all[k] + u * r_all[k, None] * rng.choice([1.0, 1.0, 3.0, 0.5], n)[:, None]
+        o[: n // 8] = org + rng.normal(size=(n // 8, 3)) * reach          # some far out (but admitted)
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o32, d32 = o.astype(np.float32), d.astype(np.float32)
+        o_rel = (o32 - org.astype(np.float32)).astype(np.float32)
+        assert ((o_rel.astype(np.float64) ** 2).sum(1) <= float(o2_max)).all()
+        dsk = (d32 * s_ds).astype(np.float32)
+        nk0 = (-(o_rel * dsk).sum(1)).astype(np.float32)
+        k1p = ((o_rel * o_rel).sum(1).astype(np.float32) * s_nk2slack).astype(np.float32)
+
+        def pack(v, w, tail):                                                   # the 16 K slots of a B operand, per ray
+            hi = bf16_round(v)
+            lo = bf16_round(v - hi)
+            w0, w1, w2 = split3(w)
+            t3 = np.full((len(v), 3), tail, np.float32)
+            return np.concatenate([hi, lo, hi, np.stack([w0, w1, w2], 1), t3, np.zeros((len(v), 1), np.float32)], 1).astype(np.float64)
+        B1 = pack(dsk, nk0, 0.0)
+        B2 = pack((o_rel * s_2k2).astype(np.float32), k1p, neg_k2)
+        g = A @ B1.T                                                            # [records, rays]
+        assert np.abs(g[real]).max() <= 0.5
+        acc = A @ B2.T + np.clip(g * np.abs(g), 0.0, 1.0)
+        cand = ~(acc < 0)
+        # geometry in double, from the records themselves
+        oc = o[None, :, :] - rec[:, None, :3]
+        b = (oc * d[None]).sum(-1)
+        R2 = -rec[:, 3][:, None]
+        c_infl = (oc * oc).sum(-1) - R2
+        c_encl = (oc * oc).sum(-1) - R2 / (INFLATE * INFLATE)
+        touches_fwd = (b * b - c_encl >= 0) & ((b < 0) | (c_encl < 0))
+        must = real[:, None] & touches_fwd
+        assert not (must & ~cand).any(), (name, int((must & ~cand).sum()))
+        assert not cand[~real].any(), name                                      # padding records are never candidates
+        dropped_on_line = real[:, None] & ~cand & (b * b - c_infl >= 0)
+        R2s = np.where(real[:, None], R2, 1.0)
+        behind = (b >= -1e-3 * np.sqrt(R2s)) & (c_infl > -1e-3 * R2s)           # (to the sweep's own slack)
+        assert not (dropped_on_line & ~behind).any(), name
+        assert (dropped_on_line.sum() > 0) and (cand[real].sum() > 0), name    # the test exercises both outcomes
