@@ -195,7 +195,9 @@ int mrt_read_seeds(mrt_ctx* ctx, uint32_t* out, size_t cap_u32);    /* this shar
 int mrt_redraw(mrt_ctx* ctx);
 /* `frames` x mrt_redraw: the same images.  Frames are independent until their blend, so when the (shard of the) image has
  * fewer than about two pixels per GPU lane -- a pixel is one sequential chain of samples, lib.rs:299-306's remedy for that is
- * more frames -- up to 32 consecutive frames of the stream mode share one render launch (also when a frame is very short). */
+ * more frames -- up to 32 consecutive frames of the stream mode share one render launch (also when a frame is very short).
+ * Memory: every frame of such a launch parks its colour sums in a layer of its own (16 B per pixel); a launch is held to 1 GiB
+ * of them per frame in flight (two), e.g. 32 frames of 1920x1080 or 8 of 3840x2160; the buffers are kept until mrt_destroy. */
 int mrt_render(mrt_ctx* ctx, uint32_t frames);
 int mrt_sync(mrt_ctx* ctx);
 /* Restart accumulation: zero framebuffers, frame counter 0, weight 0, shuffle [0;4]. */
@@ -247,8 +249,12 @@ int mrt_gather(mrt_ctx* const* ctxs, uint32_t n, uint32_t root);
  * root, all on the ctx's stream.  Collective: every rank calls it once per frame. */
 int mrt_gather_rccl(mrt_ctx* ctx, void* nccl_comm, uint32_t root);
 /* Full frame on the root after a gather: height*width*4 floats, row 0 = bottom (device pointer valid until the
- * next gather on this ctx; order further work after the ctx's stream). */
+ * next gather on this ctx; order further work after the ctx's stream: the next gather's copies wait for
+ * everything queued on the root's stream before it, so an asynchronous reader queued there is never overtaken). */
 void* mrt_gathered_device_ptr(mrt_ctx* root_ctx);
+/* Diagnostic: make mrt_gather on this root use the cross-device form of the copy (one hipMemcpyPeerAsync per
+ * band) even when a shard shares the root's device, so that its indexing runs on a one-GPU box. */
+int mrt_debug_set_gather_per_band(mrt_ctx* root_ctx, int enabled);
 int mrt_read_gathered(mrt_ctx* root_ctx, float* rgba_out, size_t cap_floats);   /* synchronises */
 /* host-only index math of the interleave: local row r of shard (rank, world) is this global row; rows per
  * shard; and the un-permute of a rank-major [world][local_rows][width][4] array into [height][width][4] */
@@ -297,6 +303,21 @@ int mrt_debug_mfma_scale(double reach, float scale_out[4], uint32_t* neg_k2_bf16
  * claim of DESIGN.md 4 is that this set equals {s : discriminant_s >= 0} for every ray (tests/test_gpu_superset.py). */
 int mrt_debug_world_hit(mrt_ctx* ctx, const float* rays, size_t n, int32_t* hit_out, uint32_t* candidates_out,
                         size_t cand_words_per_ray);
+/* Diagnostic: the render kernel's own forms of division and square root -- the correctly rounded expansions of `/` and
+ * sqrtf() WITHOUT their operand-scaling steps, used at every root, hit normal and normalize (shader.wgsl:286-299, :354,
+ * :381) where the operands cannot need those steps -- against hipcc's `/` and sqrtf() on the device, bit for bit (two NaNs
+ * count as equal):
+ *   mode 0: the square root of EVERY f32 with bit pattern in [bits_range[0], bits_range[1]];
+ *   mode 1: `count` quotients n / d, |n| a bit pattern drawn uniformly from [bits_range[0], bits_range[1]], |d| from
+ *           [bits_range[2], bits_range[3]] (SplitMix64 of seed and index), n of either sign; mode 2: d of either sign too.
+ * out[0] = operands tested, out[1] = operands whose results differ, out[2] = the smallest differing operand (mode 0: the
+ * bits of x; else bits(n) | bits(d) << 32; ~0 if none). */
+int mrt_debug_arith(mrt_ctx* ctx, int mode, const uint32_t bits_range[4], uint64_t count, uint64_t seed, uint64_t out[3]);
+/* The same for n caller-supplied operand pairs: out[6 i ..] = bits(x / y), bits(unscaled quotient), bits(sqrtf(x)),
+ * bits(unscaled root), and the render kernel's two per-wave operand tests evaluated on the pair -- hit normal: x a component
+ * of (at - centre), y the radius; normalize: x the squared length, y a component -- 1 = unscaled forms, 0 = the wave takes
+ * the literal `/` and sqrtf(). */
+int mrt_debug_arith_pairs(mrt_ctx* ctx, const float* x, const float* y, size_t n, uint32_t* out);
 /* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
 int mrt_debug_sweep_variant(mrt_ctx* ctx);
 /* Diagnostic A/B switch: 0 makes mrt_render launch every frame on its own. */

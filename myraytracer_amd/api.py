@@ -392,6 +392,23 @@ class State:
         bits = np.unpackbits(cand.view(np.uint8), axis=1, bitorder="little")[:, :n_spheres].astype(bool)
         return hit[:, 0].copy(), hit[:, 1].copy().view(np.float32), bits
 
+    def debug_arith(self, mode: int, bits_range: Sequence[int], count: int = 0, seed: int = 1):
+        """mrt_debug_arith: (tested, mismatches, smallest mismatching operand) of the kernel's unscaled sqrt (mode 0, every
+        bit pattern of bits_range[0..1]) / division (mode 1 / 2, `count` random pairs) against hipcc's own."""
+        out = (C.c_uint64 * 3)()
+        r = (C.c_uint32 * 4)(*(list(bits_range) + [0, 0, 0, 0])[:4])
+        self._check(self._L.mrt_debug_arith(self._ctx, mode, r, count, seed, out), "mrt_debug_arith")
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def debug_arith_pairs(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+        """mrt_debug_arith_pairs: (n, 6) u32 = bits of x / y, unscaled quotient, sqrtf(x), unscaled root, and the two guards."""
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        assert x.shape == y.shape and x.ndim == 1
+        out = np.zeros((len(x), 6), np.uint32)
+        self._check(self._L.mrt_debug_arith_pairs(self._ctx, x.ctypes.data, y.ctypes.data, len(x), out.ctypes.data), "mrt_debug_arith_pairs")
+        return out
+
     def debug_set_frame_batching(self, enabled: bool):
         """A/B switch: False makes render(frames) launch every frame on its own."""
         self._check(self._L.mrt_debug_set_frame_batching(self._ctx, int(enabled)), "mrt_debug_set_frame_batching")
@@ -405,6 +422,10 @@ class State:
     # -- multi-GPU (one process per GPU): RCCL gather on a caller-supplied ncclComm_t
     def gather_rccl(self, nccl_comm: int, root: int = 0):
         self._check(self._L.mrt_gather_rccl(self._ctx, nccl_comm, root), "mrt_gather_rccl")
+
+    def debug_set_gather_per_band(self, enabled: bool):
+        """On the root: mrt_gather uses the cross-device form of its copies (one peer copy per band) on one device too."""
+        self._check(self._L.mrt_debug_set_gather_per_band(self._ctx, int(enabled)), "mrt_debug_set_gather_per_band")
 
     def gathered_device_ptr(self) -> int:
         return int(self._L.mrt_gathered_device_ptr(self._ctx) or 0)

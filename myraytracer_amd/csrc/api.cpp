@@ -706,6 +706,7 @@ void mrt_destroy(mrt_ctx* c) {
     if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->d_gather_stage) (void)hipFree(c->d_gather_stage);
     if (c->ev_gather) (void)hipEventDestroy(c->ev_gather);
+    if (c->ev_gather_root) (void)hipEventDestroy(c->ev_gather_root);
     for (uint32_t i = 0; i < mrt_ctx::kEventRing; i++) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -1042,7 +1043,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch) {
         p.pix_stride = (uint32_t)n;
         for (uint32_t b = 0; b < batch; b++) {
             if (b == 0) std::memcpy(p.layer_shuffle[0], c->locals.rng_shuffle, 16);
-            else mrt_frame_shuffle(c->seed, c->frames_done == UINT32_MAX ? UINT32_MAX : c->frames_done + b, p.layer_shuffle[b]);
+            else mrt_frame_shuffle(c->seed, c->frames_done > UINT32_MAX - b ? UINT32_MAX : c->frames_done + b, p.layer_shuffle[b]);   // saturating, as :300
         }
     }
     p.pix_acc = S.d_pix_acc;
@@ -1071,6 +1072,8 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch) {
         }
     }
     const uint32_t ev = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
+    if (S.queue_dirty) HIP_TRY(c, hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), S.stream));   // an earlier frame of this slot failed half way
+    S.queue_dirty = true;                        // until this frame's last finalize pass has been queued
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], S.stream));
     int e = mrt::launch_render(p, false, c->n_waves, S.stream);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
@@ -1092,6 +1095,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch) {
         mrt_frame_shuffle(c->seed, c->frames_done, c->locals.rng_shuffle);    // :305 (deterministic stand-in)
     }
     HIP_TRY(c, hipEventRecord(S.finalize_done, c->stream));
+    S.queue_dirty = false;
     S.cost_valid = true;
     c->frame_seq++;
     c->shuffle_overridden = false;
@@ -1107,6 +1111,7 @@ int mrt_redraw(mrt_ctx* c) {
 // sums), so when the shard has too few pixels to fill the GPU -- a pixel is one sequential chain of samples -- one launch
 // renders up to kMaxFrameBatch consecutive frames: a lane that finishes a pixel of frame f takes one of frame f+1.  Every
 // frame's image is the one mrt_redraw would have produced.
+static constexpr uint64_t kBatchBytes = 1ull << 30;     // colour sums of one launch's frames (x 2 slots): 32 frames of 1080p, 8 of 4K
 int mrt_render(mrt_ctx* c, uint32_t frames) {
     if (!c) return MRT_ERR_INVALID_ARG;
     while (frames != 0) {
@@ -1118,6 +1123,9 @@ int mrt_render(mrt_ctx* c, uint32_t frames) {
             const uint64_t per_frame = (uint64_t)c->n_tiles * 64u * std::max(c->locals.samples_per_frame, 1u);
             want = std::max<uint64_t>(want, ((128ull << 20) + per_frame - 1) / per_frame);
             batch = std::min(std::min(frames, (uint32_t)mrt::kMaxFrameBatch), std::max(want, 1u));
+            // every frame of a batch parks its colour sums in a layer of its own (16 B per pixel): at most kBatchBytes per slot
+            const uint64_t layer_bytes = (uint64_t)std::max<size_t>(local_texels(c), 1) * 16u;
+            batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(batch, kBatchBytes / layer_bytes));
         }
         int st = redraw_frames(c, batch);
         if (st != MRT_OK) return st;
@@ -1291,6 +1299,45 @@ int mrt_debug_set_schedule(mrt_ctx* c, uint32_t pilot_spp, int waves_per_cu) {
     const uint32_t frames = c->frames_done;
     if (frames != 0) return fail(c, MRT_ERR_STATE, "mrt_debug_set_schedule: frames already rendered");
     return alloc_frame_buffers(c);
+}
+
+// div_unscaled / sqrt_unscaled (kernels.hip) against hipcc's `/` and sqrtf(), on the device, over whole operand ranges
+int mrt_debug_arith(mrt_ctx* c, int mode, const uint32_t bits_range[4], uint64_t count, uint64_t seed, uint64_t out[3]) {
+    if (!c || !bits_range || !out || mode < 0 || mode > 2) return MRT_ERR_INVALID_ARG;
+    if (bits_range[0] > bits_range[1] || (mode != 0 && bits_range[2] > bits_range[3]))
+        return fail(c, MRT_ERR_INVALID_ARG, "mrt_debug_arith: empty range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long* d_out = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_out, 3 * sizeof(unsigned long long)));
+    const unsigned long long init[3] = {0ull, 0ull, ~0ull};
+    hipError_t e = hipMemcpyAsync(d_out, init, sizeof init, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = (hipError_t)mrt::launch_arith_check(mode, bits_range, count, seed, d_out, c->stream);
+    unsigned long long host[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(host, d_out, sizeof host, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, MRT_ERR_HIP, "mrt_debug_arith failed: %s", hipGetErrorString(e));
+    for (int k = 0; k < 3; k++) out[k] = host[k];
+    return MRT_OK;
+}
+
+int mrt_debug_arith_pairs(mrt_ctx* c, const float* x, const float* y, size_t n, uint32_t* out) {
+    if (!c || !x || !y || !out || n > (1u << 28)) return MRT_ERR_INVALID_ARG;
+    if (n == 0) return MRT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    float* d_xy = nullptr;
+    uint32_t* d_o = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d_xy, 2 * n * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_o, 6 * n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xy, x, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_xy + n, y, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = (hipError_t)mrt::launch_arith_pairs(d_xy, d_xy + n, (uint32_t)n, d_o, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, 6 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_xy);
+    if (d_o) (void)hipFree(d_o);
+    if (e != hipSuccess) return fail(c, MRT_ERR_HIP, "mrt_debug_arith_pairs failed: %s", hipGetErrorString(e));
+    return MRT_OK;
 }
 
 int mrt_sync(mrt_ctx* c) {

@@ -63,6 +63,9 @@ struct mrt_ctx {
         uint32_t* d_tile_order = nullptr;
         uint32_t* d_sort_scratch = nullptr;    // 1024 u32 of sort workspace + the queue counter
         bool cost_valid = false;               // d_tile_cost holds a usable estimate for the current scene
+        // The tile queue's counter is left at zero by every finalize pass of the slot.  If anything between a render launch
+        // and its last finalize launch fails, it is not: the next launch on this slot resets it itself.
+        bool queue_dirty = false;
     } slot[kFrameSlots];
     hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
     bool inputs_dirty = true;
@@ -81,6 +84,10 @@ struct mrt_ctx {
     float* d_gather_stage = nullptr;
     size_t gather_bytes = 0, gather_stage_bytes = 0;
     hipEvent_t ev_gather = nullptr;
+    // on the root: "everything queued on the root's stream before this gather" -- a reader of the previous frame's
+    // d_gather among it -- which every shard's stream waits for before it overwrites d_gather (write-after-read)
+    hipEvent_t ev_gather_root = nullptr;
+    bool gather_per_band = false;              // mrt_debug_set_gather_per_band: the cross-device copy loop on one device
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

@@ -114,4 +114,9 @@ int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, 
 int launch_fill_seeds(uint32_t* seeds, uint64_t seed, uint32_t width, uint32_t height,
                       uint32_t shard_rank, uint32_t shard_world, uint32_t local_bands, void* stream);
 
+// mrt_debug_arith / mrt_debug_arith_pairs: div_unscaled / sqrt_unscaled against `/` and sqrtf() on the device
+int launch_arith_check(int mode, const uint32_t r[4], unsigned long long count, unsigned long long seed, unsigned long long* d_out,
+                       void* stream);
+int launch_arith_pairs(const float* d_x, const float* d_y, uint32_t n, uint32_t* d_out, void* stream);
+
 }  // namespace mrt

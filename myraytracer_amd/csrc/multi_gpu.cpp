@@ -49,9 +49,9 @@ int ensure_event(mrt_ctx* c) {
 // device dst_dev), on `stream`: one strided copy within a device, one peer copy per band (8 rows x W, 0.5 MB at C4; a few
 // dozen per frame) across devices -- the 1-D peer copy is the form every HIP runtime supports between any two GPUs
 hipError_t scatter_bands(float* dst_full, int dst_dev, const float* src, int src_dev, uint32_t rank, uint32_t world,
-                         uint32_t local_bands, size_t bb, hipStream_t stream) {
+                         uint32_t local_bands, size_t bb, hipStream_t stream, bool per_band = false) {
     if (local_bands == 0 || bb == 0) return hipSuccess;
-    if (dst_dev == src_dev)
+    if (dst_dev == src_dev && !per_band)
         return hipMemcpy2DAsync((char*)dst_full + (size_t)rank * bb, (size_t)world * bb, src, bb, bb, local_bands,
                                 hipMemcpyDeviceToDevice, stream);
     for (uint32_t b = 0; b < local_bands; b++) {
@@ -146,10 +146,17 @@ int mrt_gather(mrt_ctx* const* ctxs, uint32_t n, uint32_t root) {
     int st = ensure_gather_buffer(R);
     if (st != MRT_OK) return st;
     const size_t bb = band_bytes(R);
+    // Write-after-read: the shards' copies below run on the shards' OWN streams and overwrite the root's full frame.  What the
+    // caller has queued on the root's stream so far -- a consumer of the previous gather's mrt_gathered_device_ptr among it --
+    // must have finished first: an event on the root's stream, which every other stream waits for before its copies.
+    HIP_TRY(R, hipSetDevice(R->device));
+    if (!R->ev_gather_root) HIP_TRY(R, hipEventCreateWithFlags(&R->ev_gather_root, hipEventDisableTiming));
+    HIP_TRY(R, hipEventRecord(R->ev_gather_root, R->stream));
     for (uint32_t i = 0; i < n; i++) {
         mrt_ctx* c = ctxs[i];
         if ((st = ensure_event(c)) != MRT_OK) { if (c != R) R->err = c->err; return st; }
         HIP_TRY(R, hipSetDevice(c->device));
+        if (c->stream != R->stream) HIP_TRY(R, hipStreamWaitEvent(c->stream, R->ev_gather_root, 0));
         if (c->device != R->device) {
             // direct peer writes over xGMI; "already enabled" is fine, and without peer access HIP stages the copy
             hipError_t pe = hipDeviceEnablePeerAccess(R->device, 0);
@@ -157,7 +164,7 @@ int mrt_gather(mrt_ctx* const* ctxs, uint32_t n, uint32_t root) {
         }
         // on the SOURCE's stream, i.e. after its finalize pass; the root's stream then waits for every shard
         const float* src = c->d_fb[c->target ^ 1];
-        HIP_TRY(R, scatter_bands(R->d_gather, R->device, src, c->device, i, n, c->local_bands, bb, c->stream));
+        HIP_TRY(R, scatter_bands(R->d_gather, R->device, src, c->device, i, n, c->local_bands, bb, c->stream, R->gather_per_band));
         HIP_TRY(R, hipEventRecord(c->ev_gather, c->stream));
     }
     HIP_TRY(R, hipSetDevice(R->device));
@@ -195,6 +202,8 @@ int mrt_gather_rccl(mrt_ctx* c, void* nccl_comm, uint32_t root) {
         HIP_TRY(c, hipMalloc((void**)&c->d_gather_stage, stage_need ? stage_need : 16));
         c->gather_stage_bytes = stage_need;
     }
+    // (no write-after-read hazard here: the receives into the staging buffer and the un-permute into d_gather are all on the
+    // context's own stream, i.e. behind whatever the caller queued there to read the previous frame)
     if ((st = nccl_try(N.group_start(), "ncclGroupStart")) != MRT_OK) return st;
     for (uint32_t r = 0; r < world; r++) {
         if (r == root) continue;
@@ -207,6 +216,12 @@ int mrt_gather_rccl(mrt_ctx* c, void* nccl_comm, uint32_t root) {
         const float* from = r == root ? src : c->d_gather_stage + (size_t)r * local_floats;
         HIP_TRY(c, scatter_bands(c->d_gather, c->device, from, c->device, r, world, c->local_bands, bb, c->stream));
     }
+    return MRT_OK;
+}
+
+int mrt_debug_set_gather_per_band(mrt_ctx* root, int enabled) {
+    if (!root) return MRT_ERR_INVALID_ARG;
+    root->gather_per_band = enabled != 0;
     return MRT_OK;
 }
 

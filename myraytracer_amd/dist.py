@@ -80,3 +80,14 @@ def framebuffer_tensor(state, device: Optional[torch.device] = None) -> torch.Te
         raise RuntimeError("no framebuffer")
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     return torch.as_tensor(_DevicePtr(ptr, (rows, width, 4)), device=dev)
+
+
+def gathered_tensor(root_state, device: Optional[torch.device] = None) -> torch.Tensor:
+    """Zero-copy torch view of the full frame the last mrt_gather / mrt_gather_rccl assembled on this root State
+    ([height, W, 4] f32, row 0 = bottom).  Valid until the next gather; ops on it must run on the State's stream (the next
+    gather's copies wait for what that stream holds, see mrt_gathered_device_ptr)."""
+    ptr = root_state.gathered_device_ptr()
+    if not ptr:
+        raise RuntimeError("nothing gathered yet")
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.as_tensor(_DevicePtr(ptr, (root_state.args.height, root_state.args.width, 4)), device=dev)

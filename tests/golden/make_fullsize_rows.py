@@ -12,7 +12,7 @@ counters (samples, world_hit_calls, rng_draws), which is what bench.py's headlin
 Like every vector under tests/golden/ these pin the ORACLE; parity with the reference's own floating point
 is unpinned (oracle/rt_oracle.h).
 
-Run from the repo root:  python tests/golden/make_fullsize_rows.py [--threads N] [--only c3,c4,c5]
+Run from the repo root:  python tests/golden/make_fullsize_rows.py [--threads N] [--only c3,c4,c5,c5ctr]
 """
 import argparse
 import json
@@ -40,6 +40,10 @@ CONFIGS = {
                rows=[5, 1080, 2000], whole_frame_counters=False),
     "c5": dict(scene="stress", width=1920, height=1080, spp=4096, depth=50, seed=1, frames=1,
                rows=[10, 500, 900], whole_frame_counters=False),
+    # the counter-RNG extension (blocks of 64 samples, summed blockwise): what `bench.py --config c5 --rng counter`
+    # and the 1/8 shares of an 8-GPU C5 run execute (64 block layers per pixel)
+    "c5ctr": dict(scene="stress", width=1920, height=1080, spp=4096, depth=50, seed=1, frames=1,
+                  rows=[10, 500, 900], whole_frame_counters=False, rng_mode=1),
 }
 
 
@@ -54,7 +58,7 @@ def scene_of(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--only", default="c3,c4,c5")
+    ap.add_argument("--only", default="c3,c4,c5,c5ctr")
     a = ap.parse_args()
     npz_path, json_path = os.path.join(GOLDEN, "fullsize_rows.npz"), os.path.join(GOLDEN, "fullsize_rows.json")
     arrays = dict(np.load(npz_path)) if os.path.exists(npz_path) else {}
@@ -79,7 +83,8 @@ def main():
                 t0 = time.time()
                 c = O.Counters()
                 out = O.render_frame(w, h, spp, depth, packed, ocam, seeds, O.frame_shuffle(seed, f),
-                                     O.frame_weight(f, 1.0), fb, rows=(y, y + 1), nthreads=a.threads, counters=c)
+                                     O.frame_weight(f, 1.0), fb, rows=(y, y + 1), nthreads=a.threads, counters=c,
+                                     rng_mode=cfg.get("rng_mode", 0))
                 nxt[y] = out[y]
                 arrays[f"{name}_f{f}_row{y}"] = out[y].copy()
                 d = c.as_dict()
@@ -93,7 +98,7 @@ def main():
             t0 = time.time()
             c = O.Counters()
             O.render_frame(w, h, spp, depth, packed, ocam, seeds, O.frame_shuffle(seed, 0), 0.0, None,
-                           nthreads=a.threads, counters=c)
+                           nthreads=a.threads, counters=c, rng_mode=cfg.get("rng_mode", 0))
             d = c.as_dict()
             entry["frame0_counters"] = {k: d[k] for k in ("samples", "world_hit_calls", "rng_draws")}
             print(f"{name} whole frame 0: {time.time() - t0:.1f} s, {entry['frame0_counters']}", flush=True)

@@ -127,3 +127,45 @@ def test_c5_at_4096_spp(mrt):
     assert c["samples"] == cfg["width"] * cfg["height"] * cfg["spp"]
     assert int(costs.sum()) == c["world_hit_calls"]
     _check_fixture_rows("c5", 0, fb, costs, "C5")
+
+
+def test_c5_counter_mode_at_4096_spp_whole_frame_and_eighth_shares(mrt):
+    """C5 in the counter-RNG mode (the extension `bench.py --config c5 --rng counter` and the 1/8 shares of an 8-GPU C5 run
+    execute): 64 block layers per pixel, layers x tiles queue items, the blocks of one pixel rendered by different lanes and
+    added in block order by finalize_kernel -- against oracle rows computed in the same mode (fixture `c5ctr`: the reference's
+    one stream per pixel, shader.wgsl:377-382, replaced by per-sample hashed states and blockwise sums).  Then the launch shape
+    of `--gpus 8`: the shards that own the fixture rows (rank = (row / 8) mod 8), whose packed bands must hold the same rows."""
+    cfg = META["c5ctr"]
+    assert cfg["rng_mode"] == 1
+    sc, cam = _scene(mrt, cfg["scene"])
+    assert len(sc) == cfg["n_spheres"] == 10001
+    args = mrt.Args(cfg["width"], cfg["height"], cfg["spp"], cfg["depth"], 1.0)
+    with mrt.State(args, seed=cfg["seed"]) as st:
+        st.set_world(sc)
+        st.set_camera(cam)
+        st.set_rng_mode(1)
+        st.redraw()
+        st.sync()
+        fb, c, costs = st.read_framebuffer(), st.read_counters(), st.debug_read_pixel_costs()
+    assert c["samples"] == cfg["width"] * cfg["height"] * cfg["spp"]
+    assert int(costs.sum()) == c["world_hit_calls"]
+    _check_fixture_rows("c5ctr", 0, fb, costs, "C5 counter mode")
+    # and it is a different image from the stream mode's (same seed): the fixture is not the stream fixture by accident
+    assert not np.array_equal(ROWS["c5ctr_f0_row500"], ROWS["c5_f0_row500"])
+    world = 8
+    for rc in cfg["row_counters"][0]:
+        y = rc["row"]
+        rank, lrow = (y // 8) % world, (y // 8) // world * 8 + y % 8
+        assert mrt.shard_global_row(lrow, rank, world) == y
+        with mrt.State(args, seed=cfg["seed"], shard=(rank, world)) as st:
+            st.set_world(sc)
+            st.set_camera(cam)
+            st.set_rng_mode(1)
+            st.redraw()
+            st.sync()
+            part, pc = st.read_framebuffer(), st.debug_read_pixel_costs()
+        ref = ROWS[f"c5ctr_f0_row{y}"]
+        assert np.array_equal(part[lrow].view(np.uint32), ref.view(np.uint32)), f"rank {rank} of 8: global row {y}"
+        assert int(pc[lrow].sum()) == rc["world_hit_calls"]
+        band = slice(lrow - lrow % 8, lrow - lrow % 8 + 8)
+        assert np.array_equal(part[band].view(np.uint32), fb[y - y % 8:y - y % 8 + 8].view(np.uint32)), f"rank {rank}: band of row {y}"

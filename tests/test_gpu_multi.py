@@ -54,6 +54,65 @@ def test_gather_equals_unsharded(mrt, world, root, w, h):
             st.close()
 
 
+def test_gather_per_band_copies_on_one_device(mrt):
+    """The cross-device form of mrt_gather's copies (one hipMemcpyPeerAsync per band: what runs between two GPUs) forced
+    onto one device, so that its band indexing is exercised on a one-GPU box: same image, uneven band counts included."""
+    sc, cam = mrt.scene_cover(1, True)
+    for world, root, w, h in ((3, 1, 70, 45), (8, 0, 64, 200), (5, 4, 33, 7)):
+        ref, _, _ = gpu_render(mrt, sc, cam, w, h, 2, 50, 9)
+        states = _sharded_states(mrt, sc, cam, mrt.Args(w, h, 2, 50), 9, world)
+        try:
+            states[root].debug_set_gather_per_band(True)
+            mrt.gather(states, root)
+            got = states[root].read_gathered()
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+        finally:
+            for st in states:
+                st.close()
+
+
+def test_gather_does_not_overtake_a_reader_on_the_roots_stream(mrt):
+    """Write-after-read on the root's full frame: an asynchronous consumer of mrt_gathered_device_ptr queued on the root's
+    stream (here: a long sleep kernel, then a copy) must see frame k although frame k+1 is rendered and gathered right
+    behind it -- the shards' copies run on the shards' own streams and wait for an event of the root's stream."""
+    import torch
+    from myraytracer_amd import dist as mdist
+    sc, cam = mrt.scene_cover(1, True)
+    w, h, world, root = 128, 72, 3, 1
+    ref1, _, _ = gpu_render(mrt, sc, cam, w, h, 2, 50, 4, frames=1)
+    ref2, _, _ = gpu_render(mrt, sc, cam, w, h, 2, 50, 4, frames=2)
+    assert not np.array_equal(ref1, ref2)
+    stream = torch.cuda.Stream()
+    states = []
+    try:
+        with torch.cuda.stream(stream):
+            for r in range(world):
+                st = mrt.State(mrt.Args(w, h, 2, 50), seed=4, shard=(r, world), stream=stream.cuda_stream if r == root else None)
+                st.set_world(sc)
+                st.set_camera(cam)
+                states.append(st)
+            for per_band in (False, True):
+                states[root].debug_set_gather_per_band(per_band)
+                for st in states:
+                    st.reset()
+                    st.redraw()
+                mrt.gather(states, root)
+                view = mdist.gathered_tensor(states[root])
+                torch.cuda._sleep(400_000_000)              # ~0.2 s on the root's stream, then the consumer
+                snap = view.clone()
+                for st in states:
+                    st.redraw()                             # frame k+1 on every shard, gathered at once
+                mrt.gather(states, root)
+                stream.synchronize()
+                got1 = snap.cpu().numpy()
+                got2 = states[root].read_gathered()
+                assert np.array_equal(got1.view(np.uint32), ref1.view(np.uint32)), "the reader saw bands of the next frame"
+                assert np.array_equal(got2.view(np.uint32), ref2.view(np.uint32))
+    finally:
+        for st in states:
+            st.close()
+
+
 def test_gather_validation(mrt):
     sc = mrt.scene_default()
     args = mrt.Args(32, 24, 1, 4)
