@@ -52,6 +52,9 @@ FIXED_CONFIGS = {   # BASELINE.json's other configs as stated, whatever N: (scen
     "c2": ("cover", 1200, 675, 64, 50),          # configs[1]: cover scene, Lambertian + Metal only
     "c4": ("cover-glass", 3840, 2160, 1024, 50), # configs[3]
     "c5": ("stress", 1920, 1080, 4096, 50),      # configs[4]
+    # the reference's own operating point: Args::default() renders 1 sample per frame, forever (lib.rs:27-37, :187-192,
+    # :299-306; native-runner/src/main.rs:24-25) -- one State::redraw per step; with --frames-per-step K one mrt_render(K)
+    "interactive": ("cover-glass", 1920, 1080, 1, 50),
 }
 
 
@@ -102,6 +105,97 @@ def cpu_baseline(spheres, cam, width, height, depth, seed, budget_s=15.0):
                       f"OpenMP over rows), {dt:.1f} s; rate is spp-independent, so no extrapolation is applied"}
 
 
+def source_sha16():
+    """sha256 over the sources the render path is built from: identifies the binary a profile under profiles/ describes
+    (the GPU box has no .git; scripts/summarize_profile.py stores the same value next to the counters)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("myraytracer_amd/csrc/kernels.hip", "myraytracer_amd/csrc/tile_order.hip", "myraytracer_amd/csrc/api.cpp",
+                "myraytracer_amd/csrc/mrt_internal.h", "myraytracer_amd/csrc/mrt_ctx.h", "Makefile"):
+        try:
+            h.update(open(os.path.join(ROOT, rel), "rb").read())
+        except OSError:
+            h.update(b"?")
+    return h.hexdigest()[:16]
+
+
+def abi_rccl_leg(st, dist, world, rank, steps, fence, ref_bits):
+    """N > 1, after all timing, NON-FATAL: the C ABI's own gather -- mrt_gather_rccl: grouped ncclSend / ncclRecv straight to
+    the root on an ncclComm_t this caller creates with the process's librccl (torch's), then the un-permute -- instead of
+    torch.distributed.gather: one verified frame, then `steps` timed redraw + gather steps.  Returns the report (rank 0) / None."""
+    import ctypes as C
+    path = next((l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l), None)
+    if path is None:
+        raise RuntimeError("no librccl mapped in this process")
+    rccl = C.CDLL(path)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    if rank == 0:
+        rc = rccl.ncclGetUniqueId(C.byref(uid))
+        if rc:
+            raise RuntimeError(f"ncclGetUniqueId -> {rc}")
+    box = [bytes(uid)]
+    dist.broadcast_object_list(box, src=0)
+    C.memmove(C.byref(uid), box[0], 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc:
+        raise RuntimeError(f"ncclCommInitRank -> {rc}")
+    try:
+        st.reset()
+        fence()
+        st.redraw()
+        st.gather_rccl(comm.value, 0)
+        fence()
+        verified = None
+        if rank == 0 and ref_bits is not None:
+            import numpy as np
+            verified = bool(np.array_equal(st.read_gathered().view(np.uint32), ref_bits))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st.redraw()
+            st.gather_rccl(comm.value, 0)
+        fence()
+        dt = time.perf_counter() - t0
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+    return {"verified": verified, "ms_per_step": dt / max(1, steps) * 1e3, "steps": steps, "librccl": path,
+            "what": "mrt_redraw + mrt_gather_rccl (grouped ncclSend / ncclRecv to rank 0 + un-permute) per step, behind the C ABI"}
+
+
+def abi_single_process_leg(a, n, width, height, spp, ref_rgb):
+    """N > 1, rank 0, after the process group is gone, NON-FATAL: the one-process form of the C ABI's multi-GPU path --
+    native_runner --gpus N: one context per GPU, mrt_gather's peer-to-peer band copies -- on the same workload; its image
+    (one frame) against the unsharded frame, and its own timing of 2 frames after a warm-up."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    exe = os.path.join(ROOT, "myraytracer_amd", "lib", "native_runner")
+    common = [exe, "--width", str(width), "--height", str(height), "--samples-per-frame", str(spp), "--ray-depth", str(a.depth),
+              "--seed", "1", "--scene", a.scene, "--gpus", str(n), "--rng", a.rng]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "frame.pfm")
+        r = subprocess.run(common + ["--frames", "1", "--out", out], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError((r.stderr or r.stdout).strip()[-300:])
+        raw = open(out, "rb").read()
+        head = f"PF\n{width} {height}\n-1.0\n".encode()
+        img = np.frombuffer(raw[len(head):], np.float32).reshape(height, width, 3)
+        same = bool(ref_rgb is not None and np.array_equal(img.view(np.uint32), ref_rgb))
+    r = subprocess.run(common + ["--warmup", "1", "--frames", "2"], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError((r.stderr or r.stdout).strip()[-300:])
+    rate = float(r.stdout.split("Msamples/s")[0].split()[-1])
+    return {"value": rate, "unit": "Msamples/s", "image_equals_unsharded_frame": same if ref_rgb is not None else None,
+            "what": f"native_runner --gpus {n}: one process, one mrt_ctx per GPU, mrt_gather (peer-to-peer band copies) once after 2 "
+                    "frames; wall time incl. the gather, after one warm-up frame"}
+
+
 def tests_per_launch(hits, steps, world, n_spheres):
     """What the reference's linear scan (shader.wgsl:314-329: one sphere test per sphere per world_hit) executes per launch."""
     return hits / steps / world * n_spheres if steps else 0.0
@@ -117,24 +211,27 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--scene", default="cover-glass", choices=["cover-glass", "cover", "default", "stress"])
-    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5"],
+    ap.add_argument("--config", default="c3", choices=["c1", "c2", "c3", "c4", "c5", "interactive"],
                     help="c3 (default): the headline 1920x1080x512 cover scene, weak-scaled with N; c1 / c2 / c4 / c5: BASELINE's "
-                         "configs[0] / [1] / [3] / [4] as stated")
+                         "configs[0] / [1] / [3] / [4] as stated; interactive: the reference's default Args (1 sample per frame, "
+                         "lib.rs:27-37) on the 1920x1080 cover scene")
     ap.add_argument("--frames-per-step", type=int, default=1,
                     help="frames one step renders through mrt_render (which may share a launch among the frames of a small or short "
                          "frame); 1 (default) = one mrt_redraw per step")
-    ap.add_argument("--rng", default=None, choices=["stream", "counter"],
-                    help="stream (default for c3 / c4): the reference's one Xoshiro128+ stream per pixel per frame; counter (default for c5, "
-                         "whose 8-GPU shares are pixel-starved in the stream mode): per-sample hashed states, a pixel's samples summed in "
-                         "blocks of 64 that different lanes may render (north_star's counter-based RNG; extension, DESIGN.md 4 / 7)")
+    ap.add_argument("--rng", default="stream", choices=["stream", "counter"],
+                    help="stream (default, every config): the reference's one Xoshiro128+ stream per pixel per frame; counter: per-sample "
+                         "hashed states, a pixel's samples summed in blocks of 64 that different lanes may render (north_star's "
+                         "counter-based RNG: an EXTENSION with different images, never a headline line; it keeps the pixel-starved 1/8 "
+                         "shares of an 8-GPU C5 run busy, DESIGN.md 4 / 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-abi-legs", action="store_true",
+                    help="N > 1: skip the two non-fatal legs after the timed run that drive the C ABI's own gathers (mrt_gather_rccl on a "
+                         "communicator made here; native_runner --gpus N in one process), reported as abi_rccl_gather / abi_single_process")
     ap.add_argument("--verify", action="store_true", help="N > 1: fail if the verification below fails (default: only report it)")
     ap.add_argument("--no-verify", action="store_true",
                     help="N > 1: skip the check after the timed run in which the ranks render and gather one more frame and rank 0 "
                          "compares it bit for bit with the frame it renders alone (reported as gathered_image_equals_unsharded_frame)")
     a = ap.parse_args()
-    if a.rng is None:
-        a.rng = "counter" if a.config == "c5" else "stream"
     force_dist = os.environ.get("MRT_BENCH_FORCE_DIST") == "1"      # rehearses the RCCL path on one GPU
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or force_dist):
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
@@ -172,7 +269,7 @@ def main():
     if a.config in FIXED_CONFIGS:
         a.scene, width, height, spp, a.depth = FIXED_CONFIGS[a.config]
         scaling = "strong"
-    headline = (not (a.width or a.height or a.spp) and a.frames_per_step == 1 and a.rng == ("counter" if a.config == "c5" else "stream") and
+    headline = (not (a.width or a.height or a.spp) and a.frames_per_step == 1 and a.rng == "stream" and
                 ((a.config == "c3" and a.scene == "cover-glass" and a.depth == 50 and a.gpus in WORKLOADS) or a.config in FIXED_CONFIGS))
     width, height, spp = a.width or width, a.height or height, a.spp or spp
     seed = 1
@@ -276,6 +373,7 @@ def main():
     # Verification (N > 1, after all timing): every rank restarts its accumulation and renders ONE more frame, the shards are
     # gathered as in the timed steps, and rank 0 compares the assembled image bit for bit with the frame it renders alone.
     gather_verified = None
+    ref_np = None                       # rank 0: the frame one context renders alone (frame 0 of a fresh accumulation)
     if use_dist and not a.no_verify:
         st.reset()
         fence()
@@ -290,7 +388,8 @@ def main():
                     solo.set_rng_mode(1)
                 solo.redraw()
                 solo.sync()
-                ref = torch.from_numpy(solo.read_framebuffer())
+                ref_np = solo.read_framebuffer()
+                ref = torch.from_numpy(ref_np)
             gather_verified = bool(torch.equal(one.cpu().view(torch.int32), ref.view(torch.int32)))
             if a.verify:
                 assert gather_verified, "the gathered image differs from the unsharded frame"
@@ -304,6 +403,7 @@ def main():
     else:
         rank_devices = [{"rank": 0, "local_rank": local_rank, "device": torch.cuda.get_device_name(device)}]
 
+    out = None
     if rank == 0:
         total_samples = float(width) * height * spp * a.steps * a.frames_per_step
         assert samples_counted == total_samples or a.steps == 0, (samples_counted, total_samples)
@@ -328,6 +428,13 @@ def main():
         # consecutive frames' render kernels overlap (frames in flight), so a kernel's own duration
         # (roofline.kernel_ms) exceeds the wall time per step; the VALU fractions use the wall time
         kernel_s = elapsed_max / max(1, a.steps)
+        src_now = source_sha16()
+        label = "custom" if (a.width or a.height or a.spp) else a.config.upper()
+        if a.rng == "counter":
+            label += " (counter-RNG extension)"
+        if a.frames_per_step != 1:
+            label += f" ({a.frames_per_step} frames per step through mrt_render)"
+        prof_src = (pmc or {}).get("source_sha16")
         scene_names = {"cover-glass": "RTIOW cover scene with Dielectric + defocus blur", "cover": "RTIOW cover scene (Lambertian + Metal)",
                        "stress": "10k-sphere stress scene (100 x 100 jittered grid + ground, 80/15/5 % L/M/D)",
                        "default": "the reference's shipped 4-sphere scene"}
@@ -336,23 +443,38 @@ def main():
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed_max / max(1, a.steps) * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{a.config.upper() if (headline or a.rng == 'counter') else 'custom'}: {scene_names[a.scene]} ({n_spheres} spheres, scene_seed 1), "
+            "config": {"workload": f"{label}: {scene_names[a.scene]} ({n_spheres} spheres, scene_seed 1), "
                                    f"{width}x{height}, {spp} spp per frame, depth {a.depth}, seed {seed}; "
                                    f"1 step = {a.frames_per_step} redraw(s) (+ RCCL gather to rank 0 when n_gpus > 1)",
                        "headline": headline, "sharding": f"interleaved 8-row bands over {world} GPU(s)",
                        "rng": {"stream": "one Xoshiro128+ stream per pixel per frame (the reference's, shader.wgsl:377-382)",
                                "counter": "per-sample hashed states, blocks of 64 samples (extension)"}[a.rng]},
+            "source_sha16": src_now,
             "rccl_world_size": dist.get_world_size() if use_dist else 1, "backend": backend if use_dist else None,
             "ranks": rank_devices,
             "scene_upload_ms": st.last_set_world_ms(),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/hbm_traffic.json: rocprofv3 --pmc passes of this command (profiles/README.md), "
-                                           "NOT measured in this run" if traffic is not None else None,
+            # north_star's roofline: HBM.  `achieved` / `frac` = algorithmic bytes of one launch over the WALL time per step (two
+            # frames are in flight, so a launch's own duration -- kernel_ms, HIP events on its stream -- spans about two steps;
+            # the per-launch figures are kept beside it).  Tiny by construction: 0.06 byte per sample; see valu_issue.
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / kernel_s * 1e-9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes / kernel_s * 1e-9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "achieved_per_overlapped_launch": achieved, "frac_per_overlapped_launch": achieved / HBM_PEAK_GBS,
+                         "traffic_source": (f"profiles/hbm_traffic.json: rocprofv3 --pmc passes of this command (profiles/README.md), NOT measured "
+                                            f"in this run; profiled source {prof_src or '?'}, this run's source {src_now}") if traffic is not None else None,
                          "kernel": "mrt::render_kernel", "kernel_ms": kernel_ms_max,
-                         "note": "kernel_ms = mean launch duration (HIP events on its stream); launches of consecutive "
-                                 "frames overlap, so it is longer than ms_per_step",
+                         "note": "achieved = algorithmic bytes per launch / wall time per step; kernel_ms = mean launch duration (HIP events on "
+                                 "its stream): launches of consecutive frames overlap (profiles/*_launch_timeline.txt), so it is about twice "
+                                 "ms_per_step and frac_per_overlapped_launch about half of frac",
                          "algorithmic_bytes_per_launch": alg_bytes},
+            # the bound that binds: VALU issue slots.  frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x cycles), per serialised launch
+            # under rocprofv3 --pmc (committed profile of this command); ceiling = what a pure sweep / a brute-force frame reach
+            "valu_issue": ({"frac": pmc.get("issue_frac"), "peak": 1.0, "measured_ceiling": [0.865, 0.886],
+                            "ceiling_source": "profiles/r01_ubench_pmc.txt (sweep microbenchmark; brute-force kernel over a frame)",
+                            "thread_utilisation": pmc.get("thread_utilisation"),
+                            "valu_insts_per_wave_bounce": pmc.get("valu_insts_per_wave_bounce"),
+                            "source": pmc.get("source"), "profiled_source_sha16": prof_src, "this_run_source_sha16": src_now,
+                            "profile_matches_this_source": prof_src == src_now,
+                            "note": "NOT measured in this run: SQ counters of rocprofv3 --pmc passes of this command"} if pmc else None),
             "valu": {"note": "the binding resource is VALU issue, not HBM.  `executed_*` is what the kernel ran per launch (bound tests: "
                              "the swept top level of the bounding-sphere hierarchy; member discriminants only under candidate "
                              "bounds); `pmc_*` are SQ counters of a rocprofv3 --pmc pass of this command (profiles/valu_pmc.json, "
@@ -389,11 +511,50 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spheres, cam, width, height, a.depth, seed)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+
+    # ---- N > 1: the C ABI's own gathers on the same workload, after everything that is timed for `value`.  Non-fatal by
+    # construction: any exception becomes {"error": ...}; a hang (a collective that never completes) is ended by a watchdog
+    # that prints the line already computed and exits 0 -- the measured curve never depends on these legs.
+    import threading
+    printed = threading.Lock()
+
+    def emit(extra=None):
+        if rank == 0 and out is not None and printed.acquire(blocking=False):
+            if extra:
+                out.update(extra)
+            print(json.dumps(out), flush=True)
+
+    if use_dist and backend == "nccl" and not a.no_abi_legs:
+        def give_up():
+            emit({"abi_rccl_gather": {"error": "timed out after 240 s (watchdog); the line above it was already final"}})
+            os._exit(0)
+        dog = threading.Timer(240.0, give_up)
+        dog.daemon = True
+        dog.start()
+        leg = None
+        try:
+            leg = abi_rccl_leg(st, dist, world, rank, min(a.steps, 5), fence,
+                               ref_np.view(np.uint32) if ref_np is not None else None)
+        except Exception as e:          # noqa: BLE001 -- non-fatal by design
+            leg = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+        if rank == 0:
+            out["abi_rccl_gather"] = leg
     st.close()
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:               # noqa: BLE001
+            pass
+    if rank == 0 and use_dist and backend == "nccl" and world > 1 and not a.no_abi_legs:
+        try:
+            out["abi_single_process"] = abi_single_process_leg(a, world, width, height, spp,
+                                                               ref_np[..., :3].copy().view(np.uint32) if ref_np is not None else None)
+        except Exception as e:          # noqa: BLE001
+            out["abi_single_process"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    emit()
+
 
 
 if __name__ == "__main__":

@@ -1,7 +1,8 @@
 // Headless counterpart of native-runner/src/main.rs: the same five flags
 // (main.rs:20-31: --width --height --samples-per-frame --ray-depth --max-framebuffer-weight)
 // driving the MI355X backend through the C ABI, plus what a windowless run needs
-// (--frames, --seed, --scene, --out, --device).  The reference renders forever into a
+// (--frames, --seed, --scene, --out, --device; --warmup N renders N untimed frames first and restarts the accumulation;
+// --rng stream|counter selects the RNG mode, MRT_RNG_*).  The reference renders forever into a
 // window (lib.rs:187-192); this renders --frames frames and writes the image.
 // --gpus N (devices 0..N-1) or --devices a,b,c tile-shards the frame over several GPUs from this one
 // process: one context per GPU, interleaved 8-row bands, one mrt_gather per frame onto the first device
@@ -19,7 +20,7 @@
 static void usage() {
     std::fprintf(stderr,
         "usage: native_runner [--width N] [--height N] [--samples-per-frame N] [--ray-depth N]\n"
-        "                     [--max-framebuffer-weight F] [--frames N] [--seed N]\n"
+        "                     [--max-framebuffer-weight F] [--frames N] [--warmup N] [--seed N] [--rng stream|counter]\n"
         "                     [--scene default|cover|cover-glass|stress | --scene-file FILE] [--save-scene FILE]\n"
         "                     [--out FILE.pfm|FILE.ppm|FILE.png] [--device N | --gpus N | --devices a,b,...]\n");
 }
@@ -27,7 +28,7 @@ static void usage() {
 int main(int argc, char** argv) {
     mrt_args args;
     mrt_args_default(&args);
-    uint32_t frames = 1; uint64_t seed = 1; int device = 0;
+    uint32_t frames = 1, warmup = 0, rng_mode = MRT_RNG_PIXEL_STREAM; uint64_t seed = 1; int device = 0;
     std::string scene = "default", scene_file, save_scene, out;
     std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
@@ -43,6 +44,11 @@ int main(int argc, char** argv) {
         else if (a == "--ray-depth") args.ray_depth = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
         else if (a == "--max-framebuffer-weight") args.max_framebuffer_weight = std::strtof(v.c_str(), nullptr);
         else if (a == "--frames") frames = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+        else if (a == "--warmup") warmup = (uint32_t)std::strtoul(v.c_str(), nullptr, 10);
+        else if (a == "--rng") {
+            if (v == "counter") rng_mode = MRT_RNG_COUNTER;
+            else if (v != "stream") { std::fprintf(stderr, "unknown --rng %s\n", v.c_str()); return 2; }
+        }
         else if (a == "--seed") seed = std::strtoull(v.c_str(), nullptr, 10);
         else if (a == "--scene") scene = v;
         else if (a == "--scene-file") scene_file = v;
@@ -95,6 +101,13 @@ int main(int argc, char** argv) {
         if (n_gpus > 1) TRY(ctxs[i], mrt_set_shard(ctxs[i], i, n_gpus));
         TRY(ctxs[i], mrt_set_world(ctxs[i], spheres.data(), (size_t)n));
         TRY(ctxs[i], mrt_set_camera(ctxs[i], &cam));
+        if (rng_mode != MRT_RNG_PIXEL_STREAM) TRY(ctxs[i], mrt_set_rng_mode(ctxs[i], rng_mode));
+    }
+    if (warmup) {           // untimed: the tile-cost estimate, buffers and peer mappings exist afterwards
+        for (mrt_ctx* c : ctxs) TRY(c, mrt_render(c, warmup));
+        if (n_gpus > 1) TRY(ctxs[0], mrt_gather(ctxs.data(), n_gpus, 0));
+        for (mrt_ctx* c : ctxs) TRY(c, mrt_sync(c));
+        for (mrt_ctx* c : ctxs) TRY(c, mrt_reset(c));
     }
     for (mrt_ctx* c : ctxs) TRY(c, mrt_sync(c));
     auto t0 = std::chrono::steady_clock::now();

@@ -8,12 +8,13 @@ from myraytracer_amd import _lib
 a = sys.argv[1:]
 scene = a[0] if a else "cover-glass"
 w, h, spp = (int(a[1]), int(a[2]), int(a[3])) if len(a) > 3 else (1920, 1080, 32)
+frames = int(a[4]) if len(a) > 4 else 1      # > 1: one mrt_render(frames), i.e. frame batches where they apply
 sp, cam = (M.scene_cover(1, scene == "cover-glass") if scene.startswith("cover") else M.scene_stress(1, 100) if scene == "stress"
            else (M.scene_default(), None))
 with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     st.set_world(sp)
     if cam is not None: st.set_camera(cam)
-    st.render(1); st.sync()
+    st.render(frames); st.sync()
     raw = (C.c_uint64 * 16)()
     _lib.load().mrt_debug_read_counters(st._ctx, raw)
     names = ["tail: camera rays, hit records, rejection loop, scatter, normalize", "sweep", "walk: node rounds", "walk: root rounds",
