@@ -109,6 +109,36 @@ def box_pass(rays, box, t_prune=None):
     return ok
 
 
+QUAD = os.environ.get('QUAD') == '1'
+RMIN = 0.1 if scene == 'stress' else 0.2
+
+
+def sat_pass(rays, box, behind=True):
+    """the kernel's line-vs-box test: separating axes d x e_i with the slack terms, optionally + 'not entirely behind'"""
+    lo, hi = box
+    c = (0.5 * (lo + hi)).astype(np.float32).astype(float)
+    e0 = np.maximum(hi - c, c - lo)
+    e0 = np.where(np.isfinite(e0), e0, -3e38)
+    o, d = rays[:, None, :3].astype(float), rays[:, None, 3:].astype(float)
+    p = o - c[None]
+    if QUAD:
+        k2 = 1.2e-6 / RMIN
+        K = k2 * (p * p).sum(-1) + (k2 * (e0 * e0).sum(-1))[None]
+    else:
+        kpad = 1.4e-3 * np.abs(e0).sum(-1)
+        K = 2.0 ** -9 * np.abs(p).sum(-1) + kpad[None]
+    ad = np.abs(d)
+    ok = np.ones(p.shape[:2], bool)
+    for i, j, k in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+        l = p[..., j] * d[..., k] - p[..., k] * d[..., j]
+        r = e0[None, :, j] * ad[..., k] + e0[None, :, k] * ad[..., j] + K
+        ok &= np.abs(l) <= r
+    if behind:
+        reach = (e0[None] * ad).sum(-1) + K
+        ok &= (reach - (p * d).sum(-1)) >= 0
+    return ok & np.isfinite(lo[None, :, 0])
+
+
 def walk(rays, rule, t_prune=None):
     counts = []
     parent = None
@@ -117,6 +147,22 @@ def walk(rays, rule, t_prune=None):
             ok = sphere_pass(rays, recs[k], t_prune)
         elif rule == "box":
             ok = box_pass(rays, boxes[k], t_prune)
+        elif rule == "sat":
+            ok = sat_pass(rays, boxes[k], True)
+        elif rule == "satline":
+            ok = sat_pass(rays, boxes[k], False)
+        elif rule == "kernel":       # sphere sweep at the top, then SAT (with the behind test) everywhere
+            ok = sat_pass(rays, boxes[k], True)
+            if k == levels:
+                raw = sphere_pass(rays, recs[k], None)
+                counts.append(raw.sum(1).mean())
+                ok &= raw
+        elif rule == "kernelline":
+            ok = sat_pass(rays, boxes[k], False)
+            if k == levels:
+                raw = sphere_pass(rays, recs[k], None)
+                counts.append(raw.sum(1).mean())
+                ok &= raw
         else:
             ok = sphere_pass(rays, recs[k], t_prune) & box_pass(rays, boxes[k], t_prune)
         if parent is not None:
@@ -137,7 +183,7 @@ for name, rays in (("camera", cam_rays), ("bounce", bounce_rays)):
     tg = np.where(tg > 1e-3, tg, np.where(dq >= 0, -bq + np.sqrt(np.maximum(dq, 0)), 1e4))
     tg = np.where(tg > 1e-3, tg, 1e4)
     print(f"--- {name} rays: {len(rays)}, hit fraction {np.mean(hit >= 0):.2f}, hits on a small sphere {np.mean(hit > 0):.2f}")
-    for rule in ("sphere", "box", "both"):
-        for pn, tp in (("no prune", None), ("ground t", tg), ("final t (ideal order)", t_final)):
+    for rule in ("sphere", "box", "both", "sat", "satline", "kernel", "kernelline"):
+        for pn, tp in ((("no prune", None), ("ground t", tg), ("final t (ideal order)", t_final)) if rule in ("sphere", "box", "both") else (("no prune", None),)):
             c = walk(rays, rule, tp)
             print(f"{rule:7s} {pn:24s} per level top..clusters: " + " ".join(f"{x:6.2f}" for x in c) + f"   total {sum(c):6.2f}")

@@ -320,7 +320,9 @@ int mrt_debug_arith(mrt_ctx* ctx, int mode, const uint32_t bits_range[4], uint64
 int mrt_debug_arith_pairs(mrt_ctx* ctx, const float* x, const float* y, size_t n, uint32_t* out);
 /* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
 int mrt_debug_sweep_variant(mrt_ctx* ctx);
-/* Diagnostic A/B switch: 0 makes mrt_render launch every frame on its own. */
+/* Diagnostic A/B switch: 0 makes mrt_render launch every frame on its own; 1 = automatic (default); 2 / 3 force the form a
+ * batch takes -- 2: the lane that takes a pixel renders it for every frame of the batch (what short frames of a large image
+ * get), 3: the frames are layers of the tile queue (what a pixel-starved shard gets).  The images are the same. */
 int mrt_debug_set_frame_batching(mrt_ctx* ctx, int enabled);
 /* Diagnostic A/B switch: 0 queues tiles in index order instead of heaviest-first. */
 int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);

@@ -5,7 +5,9 @@ top-level Makefile).  There is no fallback of any kind: a missing library raises
 ImportError, a missing GPU makes mrt_create fail with MRT_ERR_NO_DEVICE.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRT_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libmyraytracer_amd.so")
@@ -86,11 +88,34 @@ class MrtCounters(C.Structure):
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must run ONE HIP / HSA runtime.  PyTorch-ROCm bundles its own (torch/lib/libamdhip64.so, the same soname as
+    /opt/rocm's): whichever copy is loaded first serves both torch and this library, and when /opt/rocm's comes first torch's
+    other bundled libraries still bring their own HSA runtime along -- torch then reports "No HIP GPUs are available".  So if
+    torch is installed but not imported yet, its runtime is loaded here, before ours resolves libamdhip64.so.7; the import
+    order of torch and this package then does not matter.  MRT_HIP_RUNTIME=system skips this (a process without torch)."""
+    if os.environ.get("MRT_HIP_RUNTIME") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the in-tree shared library (once) and declare the signatures."""
     global _lib
     if _lib is not None:
         return _lib
+    _one_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `make` at the repo root "

@@ -409,8 +409,9 @@ class State:
         self._check(self._L.mrt_debug_arith_pairs(self._ctx, x.ctypes.data, y.ctypes.data, len(x), out.ctypes.data), "mrt_debug_arith_pairs")
         return out
 
-    def debug_set_frame_batching(self, enabled: bool):
-        """A/B switch: False makes render(frames) launch every frame on its own."""
+    def debug_set_frame_batching(self, enabled):
+        """A/B switch: False / 0 makes render(frames) launch every frame on its own; True / 1 automatic; 2 / 3 force the
+        batch's form (2: a lane keeps its pixel for all frames of the batch, 3: frames as layers of the tile queue)."""
         self._check(self._L.mrt_debug_set_frame_batching(self._ctx, int(enabled)), "mrt_debug_set_frame_batching")
 
     def last_set_world_ms(self) -> float:

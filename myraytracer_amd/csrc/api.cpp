@@ -998,7 +998,7 @@ extern "C" {
 // pass needs a window surface and is out of scope)
 // `batch` >= 1 consecutive frames with ONE render launch (batch > 1: stream mode only, see mrt_render): the raytrace pass
 // of State::redraw for each of them, then per frame -- in order -- the blend, the swap and the weight / shuffle update.
-static int redraw_frames(mrt_ctx* c, uint32_t batch) {
+static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false) {
     if (!c->have_world) return fail(c, MRT_ERR_NO_SCENE, "mrt_redraw: no scene (call mrt_set_world first)");
     HIP_TRY(c, hipSetDevice(c->device));
     const bool counter = c->locals.rng_mode == MRT_RNG_COUNTER;
@@ -1041,6 +1041,10 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch) {
         S.cost_layers = counter ? layers : 1u;
         p.n_blocks = layers;
         p.pix_stride = (uint32_t)n;
+        // a batch of SHORT frames: the queue holds every tile once, a lane renders its pixel for all frames of the batch
+        const bool in_lane = frames_in_lane && !counter && batch > 1 && spp != 0;
+        p.queue_layers = in_lane ? 1u : layers;
+        p.lane_frames = in_lane ? batch : 1u;
         for (uint32_t b = 0; b < batch; b++) {
             if (b == 0) std::memcpy(p.layer_shuffle[0], c->locals.rng_shuffle, 16);
             else mrt_frame_shuffle(c->seed, c->frames_done > UINT32_MAX - b ? UINT32_MAX : c->frames_done + b, p.layer_shuffle[b]);   // saturating, as :300
@@ -1059,7 +1063,9 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch) {
     // first; before the slot's first frame of a scene a small pilot launch (no output) provides
     // the estimate when the frame is long enough to pay for it.  Without an estimate: index order.
     // With no more tiles than persistent waves every tile starts at once and the order cannot matter: no pilot, no sort.
-    if (c->lpt_enabled && c->n_tiles > c->n_waves) {
+    // ... nor when a pixel's chain is a handful of bounces (fewer than 4 samples per pixel and launch): three launches saved.
+    const uint32_t chain_spp = c->locals.samples_per_frame * p.lane_frames;
+    if (c->lpt_enabled && c->n_tiles > c->n_waves && chain_spp >= 4u) {
         if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
             int pe = mrt::launch_render(p, true, c->n_waves, S.stream);
             if (pe) return fail(c, MRT_ERR_HIP, "pilot launch failed: %s", hipGetErrorString((hipError_t)pe));
@@ -1127,7 +1133,15 @@ int mrt_render(mrt_ctx* c, uint32_t frames) {
             const uint64_t layer_bytes = (uint64_t)std::max<size_t>(local_texels(c), 1) * 16u;
             batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(batch, kBatchBytes / layer_bytes));
         }
-        int st = redraw_frames(c, batch);
+        // Two reasons to batch, two forms (kernels.hip): a shard with too few pixels needs more pixel chains at once -- the
+        // frames of the batch become layers of the tile queue; a frame that is merely short has pixels enough -- the lane that
+        // takes a pixel renders it for every frame of the batch (one queue atomic / seed fetch per pixel and batch).
+        // (In-lane only below 4 samples per frame: it makes a pixel's chain `batch` times longer, which costs the launch's tail
+        // more than the acquisitions cost from 8 samples up -- measured, DESIGN.md: 1 spp 5,470 -> 10,360 Msamples/s, 8 spp
+        // 11,260 -> 11,050, C2's 64 spp 11,640 -> 10,650.)
+        const bool starved = c->n_tiles < 2u * c->n_waves;
+        const bool in_lane = !starved && c->locals.samples_per_frame < 4u;
+        int st = redraw_frames(c, batch, c->batch_form == 0 ? in_lane : c->batch_form == 1);
         if (st != MRT_OK) return st;
         frames -= batch;
     }
@@ -1137,6 +1151,7 @@ int mrt_render(mrt_ctx* c, uint32_t frames) {
 int mrt_debug_set_frame_batching(mrt_ctx* c, int enabled) {
     if (!c) return MRT_ERR_INVALID_ARG;
     c->batch_frames = enabled != 0;
+    c->batch_form = enabled == 2 ? 1 : enabled == 3 ? 2 : 0;
     return MRT_OK;
 }
 
@@ -1241,7 +1256,7 @@ int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_ou
     p.shard_rank = 0; p.shard_world = 1;
     p.tiles_x = 1; p.n_tiles = (uint32_t)(n_pad / 64);
     p.tile_queue = d_queue;
-    p.n_blocks = 1; p.pix_stride = 0;
+    p.n_blocks = 1; p.pix_stride = 0; p.queue_layers = 1; p.lane_frames = 1;
     p.dbg_rays = d_rays; p.dbg_hit = d_hit; p.dbg_cand = d_cand; p.dbg_words = (uint32_t)words;
     int le = mrt::launch_debug_world_hit(p, c->n_waves, c->stream);
     if (le == 0) e = hipStreamSynchronize(c->stream);

@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         uint32_t tile = q >> 6;
         const uint32_t l = q & 63u;
         layer = 0u;
-        if (!PILOT) { layer = tile / C->n_tiles; tile -= layer * C->n_tiles; }
+        if (!PILOT && C->queue_layers > 1u) { layer = tile / C->n_tiles; tile -= layer * C->n_tiles; }
         const uint32_t tile_x = tile % C->tiles_x, band = tile / C->tiles_x;
         const uint32_t Wc = C->locals.shape[0], Hc = C->locals.shape[1];
         px = tile_x * kTileW + (l & 7u);
@@ -869,7 +869,27 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 color = color + att * v3(mixf(1.0f, 0.5f, t), mixf(1.0f, 0.7f, t), mixf(1.0f, 1.0f, t));     // :381
             }                                                                   // else: + vec3(0), :357
             s_done++;
-            if (s_done < (CTR ? (blk & 127u) : spp)) start_sample = true; else task_done = true;
+            if (s_done < (CTR ? (blk & 127u) : spp)) start_sample = true;
+            else if (!CTR && !PILOT && blk + 1u < cold_args()->lane_frames) {
+                // Stream mode, a batch of SHORT frames (mrt_render): the lane keeps its pixel for all frames of the batch --
+                // frame blk is done: park its colour sum in layer blk and start frame blk + 1 of the same pixel from the
+                // seed texel and that frame's own rng_shuffle (xoshiro128plus_load :44-47), exactly the state a launch of its
+                // own would have started from.  One acquisition (queue atomic, tile order, seed fetch from HBM) per pixel and
+                // batch instead of one per pixel and frame.
+                const KArgPtr C = cold_args();
+                PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
+                reinterpret_cast<PixAcc*>(C->pix_acc)[(size_t)blk * C->pix_stride + texel] = sa;
+                blk++;
+                const uint4 sd = reinterpret_cast<const uint4*>(C->seeds)[texel];
+                rng.s0 = sd.x ^ C->layer_shuffle[blk][0];
+                rng.s1 = sd.y ^ C->layer_shuffle[blk][1];
+                rng.s2 = sd.z ^ C->layer_shuffle[blk][2];
+                rng.s3 = sd.w ^ C->layer_shuffle[blk][3];
+                color = v3(0.0f, 0.0f, 0.0f);
+                s_done = 0;
+                pix_trips = 0;
+                start_sample = true;
+            } else task_done = true;
         }
         MRT_STAMP(4);
 
@@ -879,7 +899,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             if (!DBG) {
                 PixAcc sa; sa.r = color.x; sa.g = color.y; sa.b = color.z; sa.cost = pix_trips;
                 const KArgPtr C = cold_args();
-                reinterpret_cast<PixAcc*>(C->pix_acc)[(CTR ? (size_t)(blk >> 7) * C->pix_stride : (size_t)0) + texel] = sa;
+                // (counter mode: the block's layer; stream mode: 0, or the last frame of a batch the lane rendered in one go)
+                reinterpret_cast<PixAcc*>(C->pix_acc)[(size_t)(CTR ? (blk >> 7) : blk) * C->pix_stride + texel] = sa;
             }
             has_task = false;
         }
@@ -890,7 +911,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(C->tile_queue, 1u);
             t = __builtin_amdgcn_readfirstlane(t);
-            const uint32_t n_layers = PILOT ? 1u : C->n_blocks;
+            const uint32_t n_layers = PILOT ? 1u : C->queue_layers;
             if (t >= C->n_tiles * n_layers) {
                 queue_empty = true;
             } else {
@@ -930,6 +951,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 s_done = 0;
                 pix_trips = 0;
                 has_task = true;
+                blk = 0u;       // stream mode: the frame of the batch this lane is on (lane_frames > 1), else unused
                 if (CTR) {      // this lane's block of the pixel's samples
                     const uint32_t first = layer * kCtrBlock;
                     const uint32_t cnt = spp > first ? (spp - first < kCtrBlock ? spp - first : kCtrBlock) : 0u;

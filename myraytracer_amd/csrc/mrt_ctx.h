@@ -98,6 +98,7 @@ struct mrt_ctx {
 
     bool shuffle_overridden = false;       // mrt_set_rng_shuffle since the last frame
     bool batch_frames = true;              // mrt_render may render several frames per launch (mrt_debug_set_frame_batching)
+    int batch_form = 0;                    // 0 automatic, 1 always "a lane keeps its pixel for the batch's frames", 2 always queue layers
     float set_world_ms = 0.0f;             // host time of the last scene upload (hierarchy build + copies)
 
     std::string err;

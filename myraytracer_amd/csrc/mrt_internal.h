@@ -87,7 +87,10 @@ struct KParams {
     // [64 b, 64 b + 64)), each summed into pix_acc[b * pix_stride + texel]; finalize adds the layers in order.  1 otherwise.
     // Stream mode: layer b = frame b of a batch of consecutive frames rendered by one launch (mrt_render), with
     // rng_shuffle layer_shuffle[b]; layer_shuffle[0] is always the (first) frame's shuffle.
-    uint32_t n_blocks, pix_stride;
+    // queue_layers = layers the tile QUEUE holds (n_tiles x queue_layers items): n_blocks, except for a batch of short frames
+    // of the stream mode, where the queue holds every tile once and the lane that takes a pixel renders it for all
+    // lane_frames frames of the batch, frame b into layer b (lane_frames = n_blocks then, 1 otherwise).
+    uint32_t n_blocks, pix_stride, queue_layers, lane_frames;
     uint32_t layer_shuffle[kMaxFrameBatch][4];
     unsigned long long* wave_log;  // diagnostic (-DMRT_STAMPS builds): 4 x u64 per wave, or null
     // mrt_debug_world_hit (the DBG instantiation of render_kernel): rays in (origin xyz, direction xyz), out: winner

@@ -15,6 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["MRT_HIP_RUNTIME"] = "system"      # a process without torch: /opt/rocm's HIP runtime for the library and for librccl
 import myraytracer_amd as M  # noqa: E402
 
 

@@ -328,6 +328,51 @@ def test_render_batches_frames_without_changing_them(mrt, oracle, frames, max_w)
     assert kernels_stepwise == frames and kernels_batched == -(-frames // 32)      # up to 32 frames per launch
 
 
+@pytest.mark.parametrize("form", [2, 3])
+@pytest.mark.parametrize("w,h,spp,depth,frames,max_w", [(61, 43, 1, 50, 37, 1.0), (56, 40, 3, 50, 9, 0.8), (40, 24, 1, 0, 5, 1.0), (40, 24, 2, 1, 33, 1.0)])
+def test_both_forms_of_a_frame_batch_give_the_stepwise_frames(mrt, oracle, form, w, h, spp, depth, frames, max_w):
+    """A batch takes one of two forms (mrt_render): its frames as layers of the tile queue (a pixel-starved shard) or -- short
+    frames of an image with pixels enough, the reference's default 1 sample per frame (lib.rs:27-37, :299-306) -- the lane
+    that takes a pixel renders it for every frame of the batch, re-seeding from the seed texel and each frame's own
+    rng_shuffle (shader.wgsl:44-47).  Forced onto small ragged images here: both give the oracle's progressive frames."""
+    sc, cam = mrt.scene_cover(1, True)
+    ref = oracle_render(oracle, sc, cam, w, h, spp, depth, seed=21, frames=frames, max_w=max_w)
+    with mrt.State(mrt.Args(w, h, spp, depth, max_w), seed=21) as st:
+        st.set_world(sc)
+        st.set_camera(cam)
+        st.debug_set_frame_batching(form)
+        st.render(frames)
+        got, c, costs = st.read_framebuffer(), st.read_counters(), st.debug_read_pixel_costs()
+        assert st.frames_done == frames and len(st.kernel_ms_history(64)) == -(-frames // 32)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+    assert c["samples"] == w * h * spp * frames
+    with mrt.State(mrt.Args(w, h, spp, depth, max_w), seed=21) as st:
+        st.set_world(sc)
+        st.set_camera(cam)
+        for _ in range(frames):
+            st.redraw()
+        cs, costs_s = st.read_counters(), st.debug_read_pixel_costs()
+    for k in ("samples", "world_hit_calls", "rng_draws"):
+        assert c[k] == cs[k], k
+    assert np.array_equal(costs, costs_s)                       # the last frame's per-pixel costs
+
+
+def test_interactive_frames_of_a_large_image_share_launches(mrt, oracle):
+    """The reference's default operating point (1 sample per frame, rendered forever: lib.rs:27-37, :187-192) at a size
+    where mrt_render chooses the in-lane form by itself (as many tiles as two per persistent wave): 40 frames of 1 spp at
+    1024 x 640, EMA weight 0.9, against the oracle's progressive loop; two launches."""
+    sc, cam = mrt.scene_cover(1, True)
+    w, h, frames = 1024, 640, 40
+    ref = oracle_render(oracle, sc, cam, w, h, 1, 50, seed=2, frames=frames, max_w=0.9)
+    with mrt.State(mrt.Args(w, h, 1, 50, 0.9), seed=2) as st:
+        st.set_world(sc)
+        st.set_camera(cam)
+        st.render(frames)
+        got = st.read_framebuffer()
+        assert len(st.kernel_ms_history(64)) == 2
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+
+
 def test_render_batching_respects_overrides_and_switch(mrt):
     """A caller-supplied rng_shuffle applies to the next frame only, which is then rendered on its own; the A/B switch turns
     batching off; either way the images agree."""
