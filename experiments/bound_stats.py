@@ -157,6 +157,11 @@ def walk(rays, rule, t_prune=None):
                 raw = sphere_pass(rays, recs[k], None)
                 counts.append(raw.sum(1).mean())
                 ok &= raw
+        elif rule == "topbox":       # sphere sweep + box filter at the top, spheres below
+            ok = sphere_pass(rays, recs[k], None)
+            if k == levels:
+                counts.append(ok.sum(1).mean())
+                ok &= sat_pass(rays, boxes[k], False)
         elif rule == "kernelline":
             ok = sat_pass(rays, boxes[k], False)
             if k == levels:
@@ -183,7 +188,7 @@ for name, rays in (("camera", cam_rays), ("bounce", bounce_rays)):
     tg = np.where(tg > 1e-3, tg, np.where(dq >= 0, -bq + np.sqrt(np.maximum(dq, 0)), 1e4))
     tg = np.where(tg > 1e-3, tg, 1e4)
     print(f"--- {name} rays: {len(rays)}, hit fraction {np.mean(hit >= 0):.2f}, hits on a small sphere {np.mean(hit > 0):.2f}")
-    for rule in ("sphere", "box", "both", "sat", "satline", "kernel", "kernelline"):
-        for pn, tp in ((("no prune", None), ("ground t", tg), ("final t (ideal order)", t_final)) if rule in ("sphere", "box", "both") else (("no prune", None),)):
+    for rule in ("sphere", "box", "both", "sat", "satline", "kernel", "kernelline", "topbox"):
+        for pn, tp in ((("no prune", None), ("ground t", tg), ("final t (ideal order)", t_final)) if rule in ("sphere", "box", "both") and os.environ.get("ALL") else (("no prune", None),)):
             c = walk(rays, rule, tp)
             print(f"{rule:7s} {pn:24s} per level top..clusters: " + " ".join(f"{x:6.2f}" for x in c) + f"   total {sum(c):6.2f}")

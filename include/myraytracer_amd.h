@@ -230,6 +230,10 @@ void* mrt_framebuffer_device_ptr(mrt_ctx* ctx);
  * world  > 1: this shard's packed rows, local_rows*width*4 floats. */
 int mrt_read_framebuffer(mrt_ctx* ctx, float* rgba_out, size_t cap_floats);
 int mrt_read_counters(mrt_ctx* ctx, mrt_counters* out);   /* accumulated since create/reset */
+/* mrt_counters::rng_draws is a per-lane counter in the kernel's rejection loop (a few VALU instructions per trip); the other
+ * counters are wave totals kept on the scalar side.  0 launches the instantiation without it (rng_draws then stops
+ * advancing); 1 (default) counts.  Takes effect at the next redraw; the images are the same. */
+int mrt_set_draw_counting(mrt_ctx* ctx, int enabled);
 
 /* ------------------------------------------------------------------ multi-GPU (no reference counterpart)
  *
@@ -289,6 +293,13 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
                               float* top_out, size_t top_cap, float* nodes_out, size_t nodes_cap,
                               uint32_t* member_index_out, size_t member_cap, uint16_t* mfma_out, size_t mfma_cap,
                               float mfma_origin_out[3], uint32_t info[10]);
+/* The same build, returning the axis-aligned boxes of the hierarchy's nodes (the walk's second bound for scenes beyond 1,024
+ * member slots): boxes_out = n_boxes x (cx, cy, cz, ex, ey, ez, kc, kpad) -- centre, half extents, and the coefficients of
+ * the test's slack K = kc X + kpad, X = |p|^2 (info[2] = 1) or |p|_1 (info[2] = 0) of the ray origin relative to the
+ * centre; a never-hit box has extents -3e38.  info[8] = {levels, n_boxes, quadratic?, box_base[0..4]}: the boxes of level
+ * k (1 <= k <= levels, the swept top last) start at box_base[k], parallel to that level's records. */
+int mrt_debug_build_boxes(const mrt_sphere* spheres, size_t n, uint32_t max_levels, uint32_t top_target, float* boxes_out,
+                          size_t boxes_cap, uint32_t info[8]);
 /* Host-side diagnostic, no GPU needed: the ray-side factors of the matrix-core sweep for a scene and camera that keep every
  * ray origin and every bound within `reach` of the sweep's origin: scale_out[4] = {stretch K, 2 K^2,
  * -(1 - 2^-13) K^2, (4 reach)^2} with K the power of two for which |K oc.ds| <= 1/2 for every admitted ray, and
@@ -318,6 +329,9 @@ int mrt_debug_arith(mrt_ctx* ctx, int mode, const uint32_t bits_range[4], uint64
  * of (at - centre), y the radius; normalize: x the squared length, y a component -- 1 = unscaled forms, 0 = the wave takes
  * the literal `/` and sqrtf(). */
 int mrt_debug_arith_pairs(mrt_ctx* ctx, const float* x, const float* y, size_t n, uint32_t* out);
+/* Diagnostic A/B switch (large scenes, > 1,024 member slots): 0 makes the walk test only the bounding spheres, as small
+ * scenes do; 1 (default) also the axis-aligned boxes of the hierarchy's nodes.  Either way the image is the same. */
+int mrt_debug_set_boxes(mrt_ctx* ctx, int enabled);
 /* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
 int mrt_debug_sweep_variant(mrt_ctx* ctx);
 /* Diagnostic A/B switch: 0 makes mrt_render launch every frame on its own; 1 = automatic (default); 2 / 3 force the form a

@@ -315,6 +315,10 @@ class State:
         """0 = the reference's per-pixel stream, 1 = per-sample counter-based states (extension)."""
         self._check(self._L.mrt_set_rng_mode(self._ctx, mode), "mrt_set_rng_mode")
 
+    def set_draw_counting(self, enabled: bool):
+        """False: launches without the per-lane RNG draw counter (counters()['rng_draws'] stops advancing); same images."""
+        self._check(self._L.mrt_set_draw_counting(self._ctx, int(enabled)), "mrt_set_draw_counting")
+
     def set_samples_per_frame(self, spp: int):
         self._check(self._L.mrt_set_samples_per_frame(self._ctx, spp), "mrt_set_samples_per_frame")
 
@@ -391,6 +395,10 @@ class State:
                     "mrt_debug_world_hit")
         bits = np.unpackbits(cand.view(np.uint8), axis=1, bitorder="little")[:, :n_spheres].astype(bool)
         return hit[:, 0].copy(), hit[:, 1].copy().view(np.float32), bits
+
+    def debug_set_boxes(self, enabled: bool):
+        """A/B switch (large scenes): False = the walk tests bounding spheres only; the image is the same."""
+        self._check(self._L.mrt_debug_set_boxes(self._ctx, int(enabled)), "mrt_debug_set_boxes")
 
     def debug_arith(self, mode: int, bits_range: Sequence[int], count: int = 0, seed: int = 1):
         """mrt_debug_arith: (tested, mismatches, smallest mismatching operand) of the kernel's unscaled sqrt (mode 0, every

@@ -78,13 +78,14 @@ void free_world(mrt_ctx* c) {
     if (c->d_spheres) (void)hipFree(c->d_spheres);
     if (c->d_clusters) (void)hipFree(c->d_clusters);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
+    if (c->d_boxes) (void)hipFree(c->d_boxes);
     if (c->d_shade) (void)hipFree(c->d_shade);
     if (c->d_top_mfma) (void)hipFree(c->d_top_mfma);
     if (c->d_member_index) (void)hipFree(c->d_member_index);
     if (c->d_vec4) (void)hipFree(c->d_vec4);
     if (c->d_f32) (void)hipFree(c->d_f32);
     if (c->d_i32) (void)hipFree(c->d_i32);
-    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_shade = nullptr; c->d_top_mfma = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
+    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_boxes = nullptr; c->d_shade = nullptr; c->d_top_mfma = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
     c->have_world = false;
 }
 
@@ -335,12 +336,94 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
 struct Hierarchy {
     std::vector<mrt::SphereRec> top, nodes;
     std::vector<uint32_t> member_index;
+    std::vector<mrt::BoxRec> boxes;           // levels 1 .. levels (the top last), level k at box_base[k]
+    uint32_t box_base[mrt::kMaxLevels + 1] = {0, 0, 0, 0, 0};
+    bool box_quad = false;
     uint32_t levels = 1, n_members = 0;       // n_members: level 0 including the direct spheres
     uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
     uint32_t n_direct = 0, direct_first = 0;
     mrt::SphereRec direct[mrt::kMaxDirect] = {};
     uint32_t direct_index[mrt::kMaxDirect] = {};
 };
+
+// The boxes of every node (levels 1 .. top), for the walk of large scenes (kernels.hip, box_may_touch).  Node j of level k
+// covers the members [j 4^k, (j+1) 4^k) of the hierarchy part of level 0.  The test is "the LINE of the ray passes the box
+// grown by K on every side", three separating axes d x e_i; it must hold whenever the reference's discriminant of a member
+// under the node is computed >= 0, i.e. whenever the line passes within h of the member's centre,
+// h^2 <= r^2 + E, E = 14 eps |oc|^2 / a: h - r <= E / (2 r) (the quadratic form) and <= sqrt(E) (the linear form).  With
+// |oc| <= |p| + |e| (p: origin - box centre, e: half extents) and |d_j| + |d_k| <= 1.4143:
+//     quadratic   K = kc |p|^2 + kpad,  kc = 1.3e-6 / r_min,  kpad = kc |e|^2 + 4.4e-14 / kc
+//     linear      K = kc |p|_1 + kpad,  kc = 1.5e-3,          kpad = kc |e|_1
+// (each with >= 9 % to spare over 1.4143 x the bound; the 4.4e-14 / kc makes the quadratic form cover the test's own
+// rounding, 4 eps |p|_1, by the inequality of the means).  The quadratic form is far smaller at moderate distances, the
+// linear one at large distances from tiny spheres; the scene takes the one that is smaller at its own reach.
+void build_boxes(const float* centers4, const float* radii, const std::vector<mrt::SphereRec>& members, Hierarchy& H) {
+    const mrt::BoxRec never_box{0.0f, 0.0f, 0.0f, -3.0e38f, -3.0e38f, -3.0e38f, 0.0f, 0.0f};
+    H.boxes.clear();
+    // the scene's reach and median radius decide the form of the slack
+    double lo_all[3] = {1e300, 1e300, 1e300}, hi_all[3] = {-1e300, -1e300, -1e300};
+    std::vector<double> rr;
+    for (size_t m = 0; m < members.size(); m++) {
+        if (!std::isfinite(members[m].neg_r2)) continue;
+        const uint32_t i = H.member_index[m];
+        rr.push_back(std::fabs((double)radii[i]));
+        for (int k = 0; k < 3; k++) {
+            lo_all[k] = std::min(lo_all[k], (double)centers4[4 * i + k]);
+            hi_all[k] = std::max(hi_all[k], (double)centers4[4 * i + k]);
+        }
+    }
+    double reach = 0.0, r_med = 0.0;
+    if (!rr.empty()) {
+        for (int k = 0; k < 3; k++) reach += (hi_all[k] - lo_all[k]) * (hi_all[k] - lo_all[k]);
+        reach = std::sqrt(reach);
+        std::nth_element(rr.begin(), rr.begin() + rr.size() / 2, rr.end());
+        r_med = rr[rr.size() / 2];
+    }
+    H.box_quad = 1.3e-6 / std::max(r_med, 1e-300) * reach < 1.5e-3 * 2.0;      // quadratic slack at the reach < 2 x the linear one
+    auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; };
+    for (uint32_t k = 1; k <= H.levels; k++) {
+        H.box_base[k] = (uint32_t)H.boxes.size();
+        const size_t n_k = k == H.levels ? H.top.size() : (size_t)((k + 1 < H.levels ? H.level_base[k + 1] : (uint32_t)H.nodes.size()) - H.level_base[k]);
+        const size_t span = (size_t)1 << (2 * k);
+        for (size_t j = 0; j < n_k; j++) {
+            const size_t m0 = j * span, m1 = std::min(members.size(), (j + 1) * span);
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, r_min = 1e300;
+            bool any = false;
+            for (size_t m = m0; m < m1; m++) {
+                if (!std::isfinite(members[m].neg_r2)) continue;
+                const uint32_t i = H.member_index[m];
+                const double r = std::fabs((double)radii[i]);
+                r_min = std::min(r_min, r);
+                for (int q = 0; q < 3; q++) {
+                    lo[q] = std::min(lo[q], (double)centers4[4 * i + q] - r);
+                    hi[q] = std::max(hi[q], (double)centers4[4 * i + q] + r);
+                }
+                any = true;
+            }
+            if (!any) { H.boxes.push_back(never_box); continue; }
+            mrt::BoxRec b;
+            float c[3], e[3];
+            double e1 = 0.0, e2 = 0.0;
+            for (int q = 0; q < 3; q++) {
+                c[q] = (float)(0.5 * (lo[q] + hi[q]));
+                const double ext = std::max(hi[q] - (double)c[q], (double)c[q] - lo[q]) * (1.0 + 1e-6) + 1e-37;   // (the 1e-6: the three roundings of the test's right-hand side)
+                e[q] = up(ext);
+                e1 += (double)e[q];
+                e2 += (double)e[q] * (double)e[q];
+            }
+            b.cx = c[0]; b.cy = c[1]; b.cz = c[2]; b.ex = e[0]; b.ey = e[1]; b.ez = e[2];
+            if (H.box_quad) {
+                const double kc = 1.3e-6 / std::max(r_min, 1e-30);
+                b.kc = up(kc);
+                b.kpad = up((double)b.kc * e2 + 4.4e-14 / kc);
+            } else {
+                b.kc = 1.5e-3f;
+                b.kpad = up(1.5e-3 * e1);
+            }
+            H.boxes.push_back(b);
+        }
+    }
+}
 
 void build_hierarchy(const float* centers4, const float* radii, uint32_t n, float factor, uint32_t max_levels,
                      uint32_t top_target, Hierarchy& H) {
@@ -411,6 +494,7 @@ void build_hierarchy(const float* centers4, const float* radii, uint32_t n, floa
     }
     while (cur.empty() || cur.size() % 32 != 0) cur.push_back(never);      // 32 = one tile of the matrix-core sweep
     H.top.swap(cur);
+    build_boxes(centers4, radii, members, H);
 }
 
 // matrix-core sweep or SGPR-fed VALU sweep for the next launch: forced by mrt_debug_set_sweep,
@@ -797,6 +881,9 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
     HIP_TRY(c, upload((void**)&c->d_spheres, recs.data(), recs.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_clusters, hier.top.data(), hier.top.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_nodes, hier.nodes.data(), hier.nodes.size() * sizeof(mrt::SphereRec)));
+    HIP_TRY(c, upload((void**)&c->d_boxes, hier.boxes.data(), hier.boxes.size() * sizeof(mrt::BoxRec)));
+    for (uint32_t k = 0; k <= mrt::kMaxLevels; k++) c->box_base[k] = hier.box_base[k];
+    c->box_quad = hier.box_quad;
     {
         std::vector<uint16_t> top_mfma;
         double max_c2 = 0.0, med_r2 = 0.0;
@@ -986,6 +1073,11 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
     p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) p.level_base[k] = c->level_base[k];
+    p.boxes = c->d_boxes;
+    for (uint32_t k = 0; k <= mrt::kMaxLevels; k++) p.box_base[k] = c->box_base[k];
+    p.box_top = c->box_base[c->levels];
+    p.use_boxes = (c->boxes_enabled && c->n_members > 1024u) ? 1u : 0u;     // large scenes only (kernels.hip: !SMALL)
+    p.box_quad = c->box_quad ? 1u : 0u;
     p.n_direct = c->n_direct; p.direct_first = c->direct_first;
     for (uint32_t k = 0; k < mrt::kMaxDirect; k++) { p.direct[k] = c->direct[k]; p.direct_index[k] = c->direct_index[k]; }
     p.cus = c->cus;
@@ -1010,6 +1102,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     p.shard_rank = c->shard_rank; p.shard_world = c->shard_world;
     p.seeds = c->d_seeds;
     p.counters = c->d_counters;
+    p.count_draws = c->count_draws ? 1u : 0u;
     p.wave_log = c->d_wave_log;
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
     p.pilot_spp = c->pilot_spp;
@@ -1221,6 +1314,25 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
     return MRT_OK;
 }
 
+int mrt_debug_build_boxes(const mrt_sphere* spheres, size_t n, uint32_t max_levels, uint32_t top_target, float* boxes_out,
+                          size_t boxes_cap, uint32_t info[8]) {
+    if ((!spheres && n) || !info || max_levels < 1 || max_levels > mrt::kMaxLevels || top_target < 1 || n > mrt::kMaxSpheres)
+        return MRT_ERR_INVALID_ARG;
+    std::vector<float> centers(4 * (n ? n : 1)), radii(n ? n : 1);
+    for (size_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) centers[4 * i + k] = spheres[i].center[k];
+        centers[4 * i + 3] = 1.0f;
+        radii[i] = spheres[i].radius;
+    }
+    Hierarchy h;
+    build_hierarchy(centers.data(), radii.data(), (uint32_t)n, 8.0f, max_levels, top_target, h);
+    info[0] = h.levels; info[1] = (uint32_t)h.boxes.size(); info[2] = h.box_quad ? 1u : 0u;
+    for (uint32_t k = 0; k <= mrt::kMaxLevels; k++) info[3 + k] = h.box_base[k];
+    if (boxes_out && boxes_cap < h.boxes.size()) return MRT_ERR_TOO_SMALL;
+    if (boxes_out) std::memcpy(boxes_out, h.boxes.data(), h.boxes.size() * sizeof(mrt::BoxRec));
+    return MRT_OK;
+}
+
 int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_out, uint32_t* cand_out, size_t cand_words) {
     if (!c || !rays || !hit_out || n == 0) return MRT_ERR_INVALID_ARG;
     if (!c->have_world) return fail(c, MRT_ERR_NO_SCENE, "mrt_debug_world_hit: no scene");
@@ -1275,6 +1387,12 @@ int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_ou
     }
     cleanup();
     if (e != hipSuccess) return fail(c, MRT_ERR_HIP, "mrt_debug_world_hit: read-back failed: %s", hipGetErrorString(e));
+    return MRT_OK;
+}
+
+int mrt_debug_set_boxes(mrt_ctx* c, int enabled) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    c->boxes_enabled = enabled != 0;
     return MRT_OK;
 }
 
@@ -1397,6 +1515,12 @@ int mrt_set_rng_shuffle(mrt_ctx* c, const uint32_t s[4]) {
 int mrt_set_rng_mode(mrt_ctx* c, uint32_t mode) {
     if (!c || mode > MRT_RNG_COUNTER) return MRT_ERR_INVALID_ARG;
     c->locals.rng_mode = mode;
+    return MRT_OK;
+}
+
+int mrt_set_draw_counting(mrt_ctx* c, int enabled) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    c->count_draws = enabled != 0;
     return MRT_OK;
 }
 

@@ -205,6 +205,33 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
     test4(g.hi, o, ds, bits);
 }
 
+// ---- the walk's second bound for large scenes: the axis-aligned box of the member spheres under a node -----------------
+// A kd-built group of spheres on a plane fills its box, not its bounding sphere: over C5's 100 x 100 grid a ray's LINE touches
+// 7.2 + 7.4 + 1.4 bounding spheres of the three levels but 1.9 + 1.9 + 0.9 boxes (experiments/bound_stats.py).  The test is the
+// line against the box grown by K on every side, through the three separating axes d x e_i:
+//     |p_j d_k - p_k d_j| <= e_j |d_k| + e_k |d_j| + K        p = o - centre, (i, j, k) cyclic
+// (necessary and sufficient for a line and a box; the parts of the line behind the origin are left to the sphere tests).
+// K = kc X + kpad, X = |p|^2 or |p|_1 (per scene), is the slack that makes it CONSERVATIVE against the reference's own
+// rounding: a member whose computed discriminant is >= 0 has the line within sqrt(r^2 + 14 eps |oc|^2 / a) of its centre,
+// i.e. up to min(14 eps |oc|^2 / (2 r), sqrt(14 eps) |oc|) beyond its surface, hence beyond its box; the host (api.cpp,
+// build_boxes) sets kc and kpad per box so that K covers 1.4143 x that for every member under the node, plus the
+// test's own rounding (4 eps |p|_1; the right-hand side's three roundings are in the extents).  A never-hit box has extents
+// -3e38: some axis' right-hand side is then hugely negative (a unit direction has a component >= 0.57).
+// 24 VALU: 3 + 3 (X) + 1 (K) + 3 x 5 + 2.
+__device__ __forceinline__ bool box_may_touch(const float4 b0, const float4 b1, V3 o, V3 d, bool quad) {
+    const float px = o.x - b0.x, py = o.y - b0.y, pz = o.z - b0.z;
+    const float X = quad ? __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px))
+                         : (__builtin_fabsf(px) + __builtin_fabsf(py)) + __builtin_fabsf(pz);
+    const float K = __builtin_fmaf(b1.z, X, b1.w);
+    const float ex = b0.w, ey = b1.x, ez = b1.y;
+    const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
+    const float sx = __builtin_fmaf(ey, adz, __builtin_fmaf(ez, ady, K)) - __builtin_fabsf(__builtin_fmaf(-pz, d.y, py * d.z));
+    const float sy = __builtin_fmaf(ez, adx, __builtin_fmaf(ex, adz, K)) - __builtin_fabsf(__builtin_fmaf(-px, d.z, pz * d.x));
+    const float sz = __builtin_fmaf(ex, ady, __builtin_fmaf(ey, adx, K)) - __builtin_fabsf(__builtin_fmaf(-py, d.x, px * d.y));
+    // separated on some axis <=> some difference is negative (finite operands: never NaN)
+    return (int32_t)(__float_as_uint(sx) | __float_as_uint(sy) | __float_as_uint(sz)) >= 0;
+}
+
 // ---- the same conservative test on the matrix cores -------------------------------------------------
 // Expanding S = (oc.ds)^2 - (oc.oc - R^2) with oc = o - C turns its two dot products into products of a
 // per-record vector with a per-ray vector:
@@ -335,6 +362,12 @@ constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 
 //   queue k        : (owner, level-k node) whose bound the owner's ray may touch, 1 <= k < P.levels
 //   queue 0        : (owner, member)     members whose discriminant is >= 0, waiting for the root tests
 constexpr uint32_t kQueueCap = 320;       // < 64 left over + 4 x 64 pushed by one round (top queue: P.gen_cap)
+// Large scenes: the owners' candidates first go to a RAW top queue (P.gen_cap entries); filter rounds test each against the
+// node's box -- kFilterPerLane candidates per lane and round: a round's cost is mostly its chain of dependent reads (item ->
+// ray -> box from L2), which two independent chains share -- and move the survivors to the top queue proper, which then only
+// needs < 64 left over + 128 from one round.
+constexpr uint32_t kFilterPerLane = 2;
+constexpr uint32_t kFilteredCap = 64u * (kFilterPerLane + 1u);
 constexpr unsigned long long kNoHitKey = 0x461C4000FFFFFFFFull;   // (bits(1e4f) << 32) | -1
 
 template <int N> struct IC { static constexpr int value = N; };
@@ -346,7 +379,9 @@ template <> struct Ent<false> { typedef uint32_t type; static constexpr uint32_t
 __host__ __device__ constexpr uint32_t lds_off_rays() { return 0u; }                   // 64 x {ox,oy,oz,dx | dy,dz, u64 hit slot}
 __host__ __device__ constexpr uint32_t lds_off_ring() { return 2048u; }                // kRingCap x u32
 __host__ __device__ constexpr uint32_t lds_off_queues() { return 2048u + 512u; }
-__host__ __device__ constexpr uint32_t lds_queue_bytes(bool small, uint32_t levels, uint32_t gen_cap) { return (levels * kQueueCap + gen_cap) * (small ? 2u : 4u); }
+__host__ __device__ constexpr uint32_t lds_queue_bytes(bool small, uint32_t levels, uint32_t gen_cap) {
+    return small ? (levels * kQueueCap + gen_cap) * 2u : (levels * kQueueCap + kFilteredCap + gen_cap) * 4u;
+}
 __host__ __device__ constexpr uint32_t lds_off_masks(bool small, uint32_t levels, uint32_t gen_cap) { return lds_off_queues() + lds_queue_bytes(small, levels, gen_cap); }
 __host__ __device__ constexpr uint32_t lds_wave_bytes(bool small, uint32_t levels, uint32_t gen_cap, uint32_t mask_chunks) {
     return lds_off_masks(small, levels, gen_cap) + mask_chunks * 128u;
@@ -538,7 +573,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         // ------------------------------------------------------------ world_hit, shader.wgsl:314-329
         const bool trace = live && depth_left != 0u;                        // lanes inside the loop of :339
         if (trace) pix_trips++;
-        if (COUNT) bounces += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(trace));
+        if (!PILOT) bounces += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(trace));
         float t_sup = 1.0e4f;                                               // :340
         int32_t best = -1;
         if (__any(trace)) {
@@ -591,7 +626,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     key0 = key < key0 ? key : key0;
                     if (DBG && hq) atomicOr(P.dbg_cand + (size_t)texel * P.dbg_words + (sidx >> 5), 1u << (sidx & 31u));
                 }
-                if (COUNT) mtests += (unsigned long long)n_direct * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(usable));
+                if (!PILOT) mtests += (unsigned long long)n_direct * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(usable));
             }
             // every lane leaves its ray where whoever picks up one of its work items finds it
             rays[2u * lane + 0u] = make_float4(o.x, o.y, o.z, d.x);
@@ -654,12 +689,18 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 uint32_t qn[kLvMax + 1];
 #pragma unroll
                 for (int lv = 0; lv <= kLvMax; lv++) qn[lv] = 0u;
+                // large scenes with boxes: the owners' candidates go to the RAW top queue first (behind the top queue proper,
+                // which is then kFilteredCap long); filter rounds move the ones whose box the ray's line touches on
+                uint32_t q_raw = 0;
+                const bool boxes = !SMALL && P.use_boxes != 0u;
+                constexpr int kRawLevel = kLvMax + 1;          // `k` of a filter round
                 for (;;) {
                     // a full round at the deepest level that has one; else refill the top queue; else
                     // a partial round at the highest level that has anything
                     int k = -1;
 #pragma unroll
                     for (int lv = 0; lv <= kLvMax; lv++) if (k < 0 && qn[lv] >= 64u) k = lv;
+                    if (!SMALL && k < 0 && q_raw >= 64u * kFilterPerLane) k = kRawLevel;
                     if (k < 0) {
                         if (total_rem != 0u) {
                             // owners unpack their masks into (owner, cluster) items at their scanned positions
@@ -667,9 +708,10 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                             uint32_t n_top = 0;
 #pragma unroll
                             for (int lv = 1; lv <= kLvMax; lv++) n_top = ((int)levels == lv) ? qn[lv] : n_top;
+                            if (boxes) n_top = q_raw;
                             const uint32_t room = gen_cap - n_top;
                             const uint32_t n_new = total_rem < room ? total_rem : room;
-                            entry_t* const dst = queues + levels * kQueueCap + n_top;
+                            entry_t* const dst = queues + levels * kQueueCap + (boxes ? kFilteredCap : 0u) + n_top;
                             // wm: the 32-record mask word being unpacked (clz = record within the word);
                             // ebase: owner bits | first record id of that word
                             entry_t* wp = dst + excl;
@@ -705,17 +747,60 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                 }
                             }
                             rem -= (uint32_t)(wp - (dst + excl));
+                            if (boxes) q_raw += n_new;
+                            else {
 #pragma unroll
-                            for (int lv = 1; lv <= kLvMax; lv++) if ((int)levels == lv) qn[lv] += n_new;
+                                for (int lv = 1; lv <= kLvMax; lv++) if ((int)levels == lv) qn[lv] += n_new;
+                            }
                             total_rem -= n_new;
                             if (total_rem != 0u) incl = wave_incl_scan(rem);
                             lds_order();
                             MRT_STAMP(6);
                             continue;
                         }
+                        if (!SMALL && q_raw != 0u) k = kRawLevel;
 #pragma unroll
                         for (int lv = kLvMax; lv >= 0; lv--) if (k < 0 && qn[lv] != 0u) k = lv;
                         if (k < 0) break;
+                    }
+                    if (!SMALL && k == kRawLevel) {
+                        // filter round: up to 128 raw candidates (owner, top node), two per lane: does the owner's line touch
+                        // the node's box?  The survivors move to the top queue proper.  (7.2 -> 1.9 items per ray at C5.)
+                        constexpr uint32_t kPer = kFilterPerLane;
+                        const uint32_t take = q_raw < 64u * kPer ? q_raw : 64u * kPer, start = q_raw - take;
+                        const entry_t* const src = queues + levels * kQueueCap + kFilteredCap;
+                        const KArgPtr C = cold_args();
+                        const float4* const bxs = reinterpret_cast<const float4*>(C->boxes) + 2u * (size_t)C->box_top;
+                        const bool quad = C->box_quad != 0u;
+                        uint32_t it[kPer];
+                        bool keep[kPer];
+                        unsigned long long km[kPer];
+#pragma unroll
+                        for (uint32_t q = 0; q < kPer; q++) it[q] = src[(lane + 64u * q < take) ? start + lane + 64u * q : 0u];
+#pragma unroll
+                        for (uint32_t q = 0; q < kPer; q++) {
+                            const uint32_t owner = it[q] >> kIdBits, node = it[q] & ((1u << kIdBits) - 1u);
+                            const float4 r0 = rays[2u * owner];
+                            const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
+                            const float4* const bx = bxs + 2u * (size_t)node;
+                            keep[q] = (lane + 64u * q < take) && box_may_touch(bx[0], bx[1], v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), quad);
+                            km[q] = __builtin_amdgcn_ballot_w64(keep[q]);
+                        }
+                        uint32_t n_top = 0;
+#pragma unroll
+                        for (int lv = 1; lv <= kLvMax; lv++) n_top = ((int)levels == lv) ? qn[lv] : n_top;
+                        uint32_t kept = 0;
+#pragma unroll
+                        for (uint32_t q = 0; q < kPer; q++) {
+                            if (keep[q]) queues[levels * kQueueCap + n_top + kept + rank_in(km[q])] = (entry_t)it[q];
+                            kept += (uint32_t)__popcll(km[q]);
+                        }
+#pragma unroll
+                        for (int lv = 1; lv <= kLvMax; lv++) if ((int)levels == lv) qn[lv] += kept;
+                        q_raw = start;
+                        lds_order();
+                        MRT_STAMP(2);           // (the stamps build books filter rounds under the node rounds' time)
+                        continue;
                     }
                     // One round at level K, K a compile-time constant in each copy: the queue counters are plain registers and
                     // the level-dependent choices (stretch, `a`, the children's base) fold away.  (With the level a run-time
@@ -747,7 +832,18 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         const SphereRec* const ch = nodes + cbase + 4u * node;
                         bool h[4];
                         unsigned long long hm[4];
-                        {
+                        if (!SMALL && inner && boxes) {
+                            // large scenes: the children's boxes instead of their bounding spheres
+                            const KArgPtr C = cold_args();
+                            const float4* const bx = reinterpret_cast<const float4*>(C->boxes) + 2u * (size_t)(C->box_base[inner ? K - 1 : 0] + 4u * node);
+                            const bool quad = C->box_quad != 0u;
+                            const float4 b[8] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], bx[6], bx[7]};
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                h[q] = box_may_touch(b[2 * q], b[2 * q + 1], ro, rd, quad);
+                                hm[q] = __builtin_amdgcn_ballot_w64(h[q]);
+                            }
+                        } else {
                             const SphereRec sr[4] = {ch[0], ch[1], ch[2], ch[3]};
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
@@ -780,7 +876,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         }
                         qn[K] = start;
                         qn[K - 1] += pushed;
-                        if (COUNT && K == 1) mtests += kClusterK * take;
+                        if (!PILOT && K == 1) mtests += kClusterK * take;
 #ifdef MRT_STAMPS
                         rounds_a_++; items_a_ += take;
 #endif
@@ -1097,14 +1193,19 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
             }
         }
         MRT_STAMP(0);
-        if (COUNT) started += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(start_sample));
+        if (!PILOT) started += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(start_sample));
     }
 
-    if (COUNT && !PILOT) {
+    // samples, world_hit calls, lane slots and member tests are wave totals kept on the scalar side (a ballot and a count per
+    // loop trip); the RNG draws are a per-lane counter in the rejection loop and only exist in the COUNT instantiation
+    // (mrt_set_draw_counting), without which rng.draws is dead code
+    if (!PILOT) {
         const unsigned long long c0 = started, c1 = bounces;      // already wave totals
-        unsigned long long c2 = rng.draws;
+        unsigned long long c2 = COUNT ? rng.draws : 0u;
+        if (COUNT) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c2 += __shfl_xor(c2, off);
+            for (int off = 32; off > 0; off >>= 1) c2 += __shfl_xor(c2, off);
+        }
         if (lane == 0 && P.counters) {
             atomicAdd(P.counters + 0, c0);
             atomicAdd(P.counters + 1, c1);
@@ -1307,8 +1408,8 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
         if (ctr) MRT_LAUNCH(false, true, true); else MRT_LAUNCH(false, true, false);
         hipLaunchKernelGGL((finalize_kernel<true>), dim3(p.n_tiles), dim3(64), 0, st, p);
     } else if (ctr) {
-        MRT_LAUNCH(true, false, true);
-    } else if (p.counters) {
+        if (p.count_draws) MRT_LAUNCH(true, false, true); else MRT_LAUNCH(false, false, true);
+    } else if (p.count_draws) {
         MRT_LAUNCH(true, false, false);
     } else {
         MRT_LAUNCH(false, false, false);

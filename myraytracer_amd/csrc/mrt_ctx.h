@@ -34,6 +34,9 @@ struct mrt_ctx {
     float* d_shade = nullptr;              // 8 floats per sphere: centre, radius, material colour, fuzz | ior
     mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
     uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
+    mrt::BoxRec* d_boxes = nullptr;        // axis-aligned boxes of the nodes of levels 1 .. top (large scenes' walk)
+    uint32_t box_base[mrt::kMaxLevels + 1] = {0, 0, 0, 0, 0};
+    bool box_quad = false, boxes_enabled = true;
     float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
     uint32_t max_levels = mrt::kMaxLevels, top_target = 256;  // hierarchy depth rule (build_hierarchy)
     uint32_t levels = 1, n_nodes = 0, n_members = 0;
@@ -48,6 +51,7 @@ struct mrt_ctx {
     float* d_fb[2] = {nullptr, nullptr};   // [target, secondary] ping-pong (lib.rs:505-543)
     int target = 0;                        // index of the buffer the NEXT redraw writes
     unsigned long long* d_counters = nullptr;
+    bool count_draws = true;               // mrt_set_draw_counting
     // Up to kFrameSlots frames may be in flight: frame n's render kernel (sort, pilot) runs on side
     // stream n % kFrameSlots and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
     // on the caller's stream.  The next frame's heavy tiles thus start while this frame's last

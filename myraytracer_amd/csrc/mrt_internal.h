@@ -25,6 +25,13 @@ constexpr uint32_t kMaxDirect = 4;       // very large spheres tested by every r
 // lib.rs:722-799) and padded to a multiple of kGroup with never-hit entries (w = +inf).
 struct alignas(16) SphereRec { float cx, cy, cz, neg_r2; };
 
+// Axis-aligned box of the member spheres under a node of the hierarchy (large scenes: the walk's second, much tighter bound
+// -- a kd-built group of spheres on a plane fills its box, not its bounding sphere): centre, half extents (measured from the
+// f32 centre, rounded up) and the two coefficients of the test's slack K = kc X + kpad (kernels.hip, box_may_touch;
+// X = |p|^2 or |p|_1 of the ray origin relative to the centre, per scene: KParams::box_quad).  A never-hit box has
+// extents -3e38.
+struct alignas(16) BoxRec { float cx, cy, cz, ex, ey, ez, kc, kpad; };
+
 // Everything one raytrace pass needs, passed by value as kernel arguments (-> SGPRs).
 // Mirrors the three bind groups of State::redraw (lib.rs:262-265): Locals + seeds,
 // World + data arrays, previous framebuffer.
@@ -60,6 +67,12 @@ struct KParams {
     const uint32_t* member_index;
     uint32_t levels, n_nodes, n_members, gen_cap;
     uint32_t level_base[kMaxLevels];
+    // boxes of the nodes of level k (1 <= k <= levels; level `levels` = the swept top) at boxes[box_base[k]], parallel to
+    // the level's records; box_top = box_base[levels].  use_boxes: the walk tests them (large scenes only); box_quad: the
+    // form of the slack.  Null / 0 for small scenes.
+    const BoxRec* boxes;
+    uint32_t box_base[kMaxLevels + 1];
+    uint32_t box_top, use_boxes, box_quad;
     // Spheres far larger than the rest (a ground sphere) are candidates for nearly every ray: up to kMaxDirect
     // of them stay out of the hierarchy and every ray evaluates their discriminant itself, from SGPRs.
     // They are the members direct_first .. direct_first + n_direct - 1 of level 0.
@@ -76,6 +89,7 @@ struct KParams {
     const float* prev;          // r_framebuffer: local_rows x W x rgba
     float* out;                 // render target
     unsigned long long* counters;  // 4 x u64 (mrt_counters) or null
+    uint32_t count_draws;       // launch the instantiation that also counts the RNG draws (mrt_set_draw_counting)
     // the frame's tile queue: persistent waves pull tiles tile_order[atomicAdd(tile_queue, 1)]
     const uint32_t* tile_order; // n_tiles tile ids, heaviest first (tile_order.hip), or null = index order
     uint32_t* tile_queue;       // one u32, zeroed before every launch

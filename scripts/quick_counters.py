@@ -22,6 +22,8 @@ def run(scene, w, h, spp, depth=50, frames=2, shard=None):
             from myraytracer_amd import _lib
             h_ = [int(x) for x in os.environ["MRT_HIER"].split(",")]
             assert _lib.load().mrt_debug_set_hierarchy(st._ctx, h_[0], h_[1]) == 0
+        if os.environ.get("MRT_BOXES"):
+            st.debug_set_boxes(os.environ["MRT_BOXES"] == "1")
         if os.environ.get("MRT_CLUSTER"):
             from myraytracer_amd import _lib
             _lib.load().mrt_debug_set_cluster_factor(st._ctx, float(os.environ["MRT_CLUSTER"]))

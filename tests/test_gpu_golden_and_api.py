@@ -373,6 +373,29 @@ def test_interactive_frames_of_a_large_image_share_launches(mrt, oracle):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
 
 
+def test_launches_without_the_draw_counter_render_the_same_frames(mrt, oracle):
+    """mrt_set_draw_counting(0) selects the instantiation without the per-lane RNG draw counter (what bench.py times): the
+    same image, samples / world_hit_calls still counted, rng_draws no longer advancing -- stream and counter RNG modes, small
+    and large scene layouts."""
+    for sc, cam, n_big in ((mrt.scene_cover(1, True) + (False,)), (mrt.scene_stress(2, 36) + (True,))):
+        for rng_mode in (0, 1):
+            w, h, spp, depth = 72, 40, 5, 30
+            cnt = oracle.Counters()
+            ref = oracle_render(oracle, sc, cam, w, h, spp, depth, seed=6, frames=2, counters=cnt, rng_mode=rng_mode)
+            with mrt.State(mrt.Args(w, h, spp, depth, 1.0), seed=6) as st:
+                st.set_world(sc)
+                st.set_camera(cam)
+                st.set_rng_mode(rng_mode)
+                st.redraw()
+                c1 = st.read_counters()
+                st.set_draw_counting(False)
+                st.redraw()
+                got, c2 = st.read_framebuffer(), st.read_counters()
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), mismatch_report(got, ref)
+            assert c2["rng_draws"] == c1["rng_draws"] and 0 < c1["rng_draws"] < cnt.rng_draws
+            assert c2["samples"] == cnt.samples == 2 * w * h * spp and c2["world_hit_calls"] == cnt.world_hit_calls
+
+
 def test_render_batching_respects_overrides_and_switch(mrt):
     """A caller-supplied rng_shuffle applies to the next frame only, which is then rendered on its own; the A/B switch turns
     batching off; either way the images agree."""

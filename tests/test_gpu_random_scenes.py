@@ -98,9 +98,10 @@ def test_hierarchy_depth_does_not_change_pixels(mrt, oracle, n):
     cam = mrt.Camera(1, (5.0, 3.0, 6.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 50.0, 0.3, 7.0)
     cnt = oracle.Counters()
     ref = oracle_render(oracle, sc, cam, 56, 32, 3, 9, 77, counters=cnt)
-    for max_levels, top_target in [(1, 64), (2, 64), (3, 8), (4, 1), (4, 64)]:
+    for max_levels, top_target, boxes in [(1, 64, True), (2, 64, True), (3, 8, True), (4, 1, True), (4, 64, True), (3, 8, False), (4, 64, False)]:
         with mrt.State(mrt.Args(56, 32, 3, 9, 1.0), seed=77) as st:
             st.debug_set_hierarchy(max_levels, top_target)
+            st.debug_set_boxes(boxes)         # the walk's box tests (default) or bounding spheres only: the same image
             st.set_world(sc)
             st.set_camera(cam)
             st.render(1)

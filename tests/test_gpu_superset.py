@@ -71,7 +71,7 @@ def _rays_for(rng, sc, n_random, n_grazing, n_inside):
     return rays.astype(np.float32)
 
 
-def _check(mrt, O, sc, rays, sweep=0, hierarchy=None, what=""):
+def _check(mrt, O, sc, rays, sweep=0, hierarchy=None, what="", boxes=True):
     packed = O.pack_world(to_oracle_spheres(O, sc))
     ref_hit, ref_t, ref_set, required = O.world_hit_batch(packed, rays)
     with mrt.State(mrt.Args(16, 16), seed=1) as st:
@@ -79,6 +79,7 @@ def _check(mrt, O, sc, rays, sweep=0, hierarchy=None, what=""):
             st.debug_set_hierarchy(*hierarchy)
         st.set_world(sc)
         st.debug_set_sweep(sweep)
+        st.debug_set_boxes(boxes)        # large scenes: the walk's box tests (the default) or bounding spheres only
         variant = st.debug_sweep_variant()
         hit, t, cand = st.debug_world_hit(rays, len(sc))
     a2 = (rays[:, 3:].astype(np.float64) ** 2).sum(1)
@@ -139,7 +140,8 @@ def test_every_hierarchy_depth(mrt, oracle, levels, top):
     sc = _random_scene(mrt, rng, 3000, rmin=0.02, rmax=0.2)
     rays = _rays_for(rng, sc, 3000, 4000, 1000)
     for sweep in (1, 2):
-        _check(mrt, oracle, sc, rays, sweep=sweep, hierarchy=(levels, top), what=f"levels {levels}, top {top}")
+        for boxes in (True, False):
+            _check(mrt, oracle, sc, rays, sweep=sweep, hierarchy=(levels, top), what=f"levels {levels}, top {top}, boxes {boxes}", boxes=boxes)
 
 
 def test_stress_scene_10k(mrt, oracle):
@@ -151,6 +153,27 @@ def test_stress_scene_10k(mrt, oracle):
     tgt = rng.uniform(sc["center"][:-1].min(0), sc["center"][:-1].max(0), (1500, 3))
     rays = np.concatenate([rays, np.concatenate([cam_o, _normalize(oracle, tgt - cam_o)], 1)], 0)
     _check(mrt, oracle, sc, rays, what="stress 10k")
+    _check(mrt, oracle, sc, rays, what="stress 10k, bounding spheres only", boxes=False)
+
+
+@pytest.mark.parametrize("spread,rmin,rmax,quad", [(2000.0, 0.01, 0.05, False), (30.0, 0.05, 0.3, True)])
+def test_box_slack_forms_large_sparse_and_large_dense_scenes(mrt, oracle, spread, rmin, rmax, quad):
+    """The box test's slack has two forms, chosen per scene (api.cpp build_boxes): quadratic in the origin's distance where
+    the spheres are large against the scene's reach, linear where they are tiny against it (1,500 spheres of radius 0.01 - 0.05
+    spread over 2,000 units: a grazing ray's discriminant error there is far more than a radius).  Both through the candidate-set
+    test, grazing rays included."""
+    from test_hierarchy_host import build_boxes
+    rng = np.random.default_rng(int(spread))
+    n = 1500
+    sc = np.zeros(n, mrt.SPHERE_DTYPE)
+    sc["center"] = (rng.uniform(-0.5, 0.5, (n, 3)) * [spread, 0.1 * spread, spread]).astype(np.float32)
+    sc["radius"] = rng.uniform(rmin, rmax, n).astype(np.float32)
+    sc["material_ty"] = 1
+    sc["albedo"] = 0.5
+    assert build_boxes(mrt, sc)["quad"] == quad
+    rays = _rays_for(rng, sc, 3000, 6000, 1000)
+    for sweep in (1, 2):
+        _check(mrt, oracle, sc, rays, sweep=sweep, what=f"spread {spread}")
 
 
 def test_origins_beyond_the_sweeps_scaling_take_the_literal_loop(mrt, oracle):

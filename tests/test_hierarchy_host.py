@@ -204,3 +204,56 @@ def test_matrix_core_sweep_algebra_is_conservative_and_drops_only_what_lies_behi
         behind = (b >= -1e-3 * np.sqrt(R2s)) & (c_infl > -1e-3 * R2s)           # (to the sweep's own slack)
         assert not (dropped_on_line & ~behind).any(), name
         assert (dropped_on_line.sum() > 0) and (cand[real].sum() > 0), name    # the test exercises both outcomes
+
+
+def build_boxes(mrt, sc, max_levels=4, top_target=256):
+    L = _lib.load()
+    sc = np.ascontiguousarray(sc, mrt.SPHERE_DTYPE)
+    info = (C.c_uint32 * 8)()
+    assert L.mrt_debug_build_boxes(sc.ctypes.data, len(sc), max_levels, top_target, None, 0, info) == 0
+    boxes = np.zeros((info[1], 8), np.float32)
+    assert L.mrt_debug_build_boxes(sc.ctypes.data, len(sc), max_levels, top_target, boxes.ctypes.data, len(boxes), info) == 0
+    return dict(levels=info[0], boxes=boxes, quad=bool(info[2]), base=[info[3 + k] for k in range(5)])
+
+
+def test_every_box_encloses_the_spheres_under_it_and_its_slack_covers_the_discriminants_rounding(mrt):
+    """The walk of large scenes tests the LINE of a ray against the axis-aligned box of the member spheres under a node, grown
+    by K = kc X + kpad (kernels.hip box_may_touch, api.cpp build_boxes).  Host-side facts the conservativeness rests on:
+    node j of level k covers the members [j 4^k, (j+1) 4^k); its box (f32 centre, extents measured from it) contains every
+    member sphere; the boxes of a level line up with the level's records (same count, never-hit where the record is); and for
+    ray origins at any distance the slack is at least 1.4143 x how far beyond a member's surface the line of a ray with a
+    computed discriminant >= 0 can pass -- min(14 eps |oc|^2 / (2 r), sqrt(14 eps) |oc|), eps = 2^-24, |oc| <= |p| + |e| --
+    plus the test's own rounding 4 eps |p|_1."""
+    eps = 2.0 ** -24
+    rng = np.random.default_rng(3)
+    for name, sc in scenes(mrt):
+        if len(sc) == 0:
+            continue
+        for max_levels, target in [(4, 256), (4, 1), (2, 8)]:
+            h, b = build(mrt, sc, max_levels, target), build_boxes(mrt, sc, max_levels, target)
+            assert b["levels"] == h["levels"]
+            c = np.asarray(sc["center"], np.float64).reshape(-1, 3)
+            r = np.abs(np.asarray(sc["radius"], np.float64))
+            n_hier = h["direct_first"] if h["n_direct"] else h["n_members"]
+            never0 = np.isinf(h["nodes"][:n_hier, 3])
+            for k in range(1, h["levels"] + 1):
+                recs = h["top"] if k == h["levels"] else h["nodes"][h["level_base"][k]:(h["level_base"][k + 1] if k + 1 < h["levels"] else len(h["nodes"]))]
+                bx = b["boxes"][b["base"][k]:(b["base"][k + 1] if k < h["levels"] else len(b["boxes"]))]
+                assert len(bx) == len(recs), (name, k)
+                span = 4 ** k
+                for j in range(len(recs)):
+                    mem = [m for m in range(j * span, min(n_hier, (j + 1) * span)) if not never0[m]]
+                    if not mem:
+                        assert bx[j, 3] < -1e38 and bx[j, 4] < -1e38 and bx[j, 5] < -1e38 and np.isinf(recs[j, 3]), (name, k, j)
+                        continue
+                    idx = h["midx"][mem]
+                    ctr, ext, kc, kpad = bx[j, :3].astype(np.float64), bx[j, 3:6].astype(np.float64), float(bx[j, 6]), float(bx[j, 7])
+                    assert (np.abs(c[idx] - ctr) + r[idx][:, None] <= ext * (1 + 1e-12)).all(), (name, k, j)
+                    assert kc > 0 and kpad > 0
+                    r_min, e2, e1 = r[idx].min(), float(np.sqrt((ext * ext).sum())), float(ext.sum())
+                    for dist in 10.0 ** rng.uniform(-4, 7, 6):
+                        # worst case over directions of p at this distance: |p|_1 in [dist, sqrt(3) dist], |p|_2 = dist
+                        oc = dist + e2
+                        need = 1.4143 * min(14 * eps * oc * oc / (2 * r_min * 0.99999), np.sqrt(14 * eps / 0.99999) * oc) + 4 * eps * np.sqrt(3) * dist
+                        have = kc * dist * dist + kpad if b["quad"] else kc * dist + kpad       # (|p|_1 >= |p|_2)
+                        assert have >= need, (name, k, j, dist, have, need, b["quad"])
