@@ -4,7 +4,7 @@ import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import myraytracer_amd as M
 
-def run(scene, w, h, spp, depth=50, frames=2, shard=None):
+def run(scene, w, h, spp, depth=50, frames=int(os.environ.get('MRT_FRAMES', '2')), shard=None):
     if scene == "cover-glass": sp, cam = M.scene_cover(1, True)
     elif scene == "cover": sp, cam = M.scene_cover(1, False)
     elif scene == "stress": sp, cam = M.scene_stress(1, 100)
@@ -39,7 +39,7 @@ def run(scene, w, h, spp, depth=50, frames=2, shard=None):
         ms_avg = sum(ms) / len(ms)
         tests = d["world_hit_calls"] * n
         share = 1.0 / shard[1] if shard else 1.0
-        print(json.dumps({"scene": scene, "n": n, "w": w, "h": h, "spp": spp, "shard": shard, "sched": os.environ.get("MRT_SCHED"), "ms": round(ms_avg, 3),
+        print(json.dumps({"scene": scene, "n": n, "w": w, "h": h, "spp": spp, "shard": shard, "sched": os.environ.get("MRT_SCHED"), "ms": round(ms_avg, 3), "ms_min": round(min(ms), 3),
                           "Msamples/s": round(w * h * spp * share / ms_avg * 1e-3, 1),
                           "bounces/sample": round(d["world_hit_calls"] / d["samples"], 3),
                           "lane_util": round(d["world_hit_calls"] / max(1, d["lane_slots"]), 4),
