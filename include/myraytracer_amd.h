@@ -329,6 +329,11 @@ int mrt_debug_arith(mrt_ctx* ctx, int mode, const uint32_t bits_range[4], uint64
  * of (at - centre), y the radius; normalize: x the squared length, y a component -- 1 = unscaled forms, 0 = the wave takes
  * the literal `/` and sqrtf(). */
 int mrt_debug_arith_pairs(mrt_ctx* ctx, const float* x, const float* y, size_t n, uint32_t* out);
+/* Diagnostic: which instantiation of the render kernel the most recent redraw launched (out[0]) and, if it was preceded by
+ * a cost-estimating pilot launch not yet reported, which one that was (out[1], else 0xFFFFFFFF): bit 0 = with the RNG draw
+ * counter, 1 = pilot, 2 = counter-RNG mode, 3 = small-scene layout, 4 = matrix-core sweep
+ * (tests/test_gpu_parity.py::test_every_render_kernel_instantiation_against_the_oracle). */
+int mrt_debug_last_launch(mrt_ctx* ctx, uint32_t out[2]);
 /* Diagnostic A/B switch (large scenes, > 1,024 member slots): 0 makes the walk test only the bounding spheres, as small
  * scenes do; 1 (default) also the axis-aligned boxes of the hierarchy's nodes.  Either way the image is the same. */
 int mrt_debug_set_boxes(mrt_ctx* ctx, int enabled);

@@ -396,6 +396,16 @@ class State:
         bits = np.unpackbits(cand.view(np.uint8), axis=1, bitorder="little")[:, :n_spheres].astype(bool)
         return hit[:, 0].copy(), hit[:, 1].copy().view(np.float32), bits
 
+    def debug_last_launch(self):
+        """(main, pilot or None): template-argument bits of the last render launch -- 1 COUNT, 2 PILOT, 4 CTR, 8 SMALL, 16 MFMA."""
+        out = (C.c_uint32 * 2)()
+        self._check(self._L.mrt_debug_last_launch(self._ctx, out), "mrt_debug_last_launch")
+        return int(out[0]), (None if out[1] == 0xFFFFFFFF else int(out[1]))
+
+    def debug_set_schedule(self, pilot_spp: int, waves_per_cu: int):
+        """Before the first redraw: samples per pixel of the pilot launch, persistent waves per CU (0 = automatic)."""
+        self._check(self._L.mrt_debug_set_schedule(self._ctx, pilot_spp, waves_per_cu), "mrt_debug_set_schedule")
+
     def debug_set_boxes(self, enabled: bool):
         """A/B switch (large scenes): False = the walk tests bounding spheres only; the image is the same."""
         self._check(self._L.mrt_debug_set_boxes(self._ctx, int(enabled)), "mrt_debug_set_boxes")

@@ -1160,7 +1160,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     const uint32_t chain_spp = c->locals.samples_per_frame * p.lane_frames;
     if (c->lpt_enabled && c->n_tiles > c->n_waves && chain_spp >= 4u) {
         if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
-            int pe = mrt::launch_render(p, true, c->n_waves, S.stream);
+            int pe = mrt::launch_render(p, true, c->n_waves, S.stream, &c->last_launch[1]);
             if (pe) return fail(c, MRT_ERR_HIP, "pilot launch failed: %s", hipGetErrorString((hipError_t)pe));
             S.cost_valid = true;
         }
@@ -1174,7 +1174,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     if (S.queue_dirty) HIP_TRY(c, hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), S.stream));   // an earlier frame of this slot failed half way
     S.queue_dirty = true;                        // until this frame's last finalize pass has been queued
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], S.stream));
-    int e = mrt::launch_render(p, false, c->n_waves, S.stream);
+    int e = mrt::launch_render(p, false, c->n_waves, S.stream, &c->last_launch[0]);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], S.stream));
     HIP_TRY(c, hipEventRecord(S.render_done, S.stream));
@@ -1387,6 +1387,13 @@ int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_ou
     }
     cleanup();
     if (e != hipSuccess) return fail(c, MRT_ERR_HIP, "mrt_debug_world_hit: read-back failed: %s", hipGetErrorString(e));
+    return MRT_OK;
+}
+
+int mrt_debug_last_launch(mrt_ctx* c, uint32_t out[2]) {
+    if (!c || !out) return MRT_ERR_INVALID_ARG;
+    out[0] = c->last_launch[0]; out[1] = c->last_launch[1];
+    c->last_launch[1] = 0xFFFFFFFFu;            // a pilot launch is reported once
     return MRT_OK;
 }
 

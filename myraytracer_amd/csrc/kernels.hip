@@ -1379,7 +1379,8 @@ static uint32_t group_lds_bytes(const KParams& p, bool small) {
 }
 
 // the persistent render waves (pilot: + its cost-only finalize) on `stream`
-int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) {
+int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream, uint32_t* which) {
+    if (which) *which = 0xFFFFFFFFu;
     if (p.n_tiles == 0 || n_waves == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     // (the queue counter is zero: reset at allocation and by every finalize pass of the slot)
@@ -1404,6 +1405,8 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream) 
         else if (mfma) hipLaunchKernelGGL((render_kernel<C_, P_, R_, false, true>), grid, block, lds, st, p);       \
         else hipLaunchKernelGGL((render_kernel<C_, P_, R_, false, false>), grid, block, lds, st, p);                \
     } while (0)
+    // which instantiation this is, for mrt_debug_last_launch: bit 0 COUNT, 1 PILOT, 2 CTR, 3 SMALL, 4 MFMA
+    if (which) *which = ((!pilot && p.count_draws) ? 1u : 0u) | (pilot ? 2u : 0u) | (ctr ? 4u : 0u) | (small ? 8u : 0u) | (mfma ? 16u : 0u);
     if (pilot) {
         if (ctr) MRT_LAUNCH(false, true, true); else MRT_LAUNCH(false, true, false);
         hipLaunchKernelGGL((finalize_kernel<true>), dim3(p.n_tiles), dim3(64), 0, st, p);

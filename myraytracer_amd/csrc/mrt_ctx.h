@@ -54,6 +54,7 @@ struct mrt_ctx {
     int target = 0;                        // index of the buffer the NEXT redraw writes
     unsigned long long* d_counters = nullptr;
     bool count_draws = true;               // mrt_set_draw_counting
+    uint32_t last_launch[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};   // mrt_debug_last_launch: the last render / pilot instantiation
     // Up to kFrameSlots frames may be in flight: frame n's render kernel (sort, pilot) runs on side
     // stream n % kFrameSlots and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
     // on the caller's stream.  The next frame's heavy tiles thus start while this frame's last

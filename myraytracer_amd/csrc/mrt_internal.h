@@ -120,7 +120,7 @@ void set_global_error(const char* msg);
 
 // host-callable launchers (kernels.hip)
 // queue reset + n_waves persistent render waves (a pilot launch also runs its cost-only finalize)
-int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream);
+int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream, uint32_t* which = nullptr);
 // the per-tile finalize pass of a rendered frame: colour sums -> framebuffer, tile costs
 int launch_finalize(const KParams& p, void* stream);
 int launch_debug_world_hit(const KParams& p, uint32_t n_waves, void* stream);

@@ -149,3 +149,40 @@ def test_counter_mode_large_scene_and_shards(mrt, oracle):
             g = mrt.shard_global_row(lr, rank, 2)
             if g < h:
                 assert np.array_equal(part[lr:lr + 8].view(np.uint32), ref[g:g + 8].view(np.uint32)), (rank, g)
+
+
+def test_every_render_kernel_instantiation_against_the_oracle(mrt, oracle):
+    """render_kernel<COUNT, PILOT, CTR, SMALL, MFMA> has 16 frame instantiations and 8 pilot ones (the pilot never counts);
+    the DBG ones (4) are what tests/test_gpu_superset.py drives.  Every one of them renders a frame here that must equal the
+    oracle's: {with, without the RNG draw counter} x {stream, counter RNG} x {small-scene layout: cover scene; large-scene
+    layout with boxes: 1,297 spheres} x {SGPR-fed VALU sweep, matrix-core sweep}, each with the schedule forced so that the
+    frame is preceded by a cost-estimating pilot launch (more tiles than persistent waves, 16 spp >= 8 x pilot spp) --
+    mrt_debug_last_launch reports which instantiations actually ran."""
+    w, h, spp, depth = 192, 136, 16, 12
+    seen_main, seen_pilot = set(), set()
+    for small in (True, False):
+        sc, cam = mrt.scene_cover(1, True) if small else mrt.scene_stress(5, 36)
+        for ctr in (0, 1):
+            cnt = oracle.Counters()
+            ref = oracle_render(oracle, sc, cam, w, h, spp, depth, seed=12, counters=cnt, rng_mode=ctr)
+            for sweep in (1, 2):
+                for count in (True, False):
+                    with mrt.State(mrt.Args(w, h, spp, depth), seed=12) as st:
+                        st.debug_set_schedule(2, 1)                 # 1 wave per CU: fewer waves than the 408 tiles
+                        st.debug_set_sweep(sweep)
+                        st.set_world(sc)
+                        st.set_camera(cam)
+                        st.set_rng_mode(ctr)
+                        st.set_draw_counting(count)
+                        st.redraw()
+                        got, c = st.read_framebuffer(), st.read_counters()
+                        main, pilot = st.debug_last_launch()
+                    what = f"small={small} ctr={ctr} sweep={sweep} count={count}"
+                    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), what + ": " + mismatch_report(got, ref)
+                    assert c["samples"] == cnt.samples and c["world_hit_calls"] == cnt.world_hit_calls, what
+                    assert c["rng_draws"] == (cnt.rng_draws if count else 0), what
+                    assert main == (1 if count else 0) | (4 if ctr else 0) | (8 if small else 0) | (16 if sweep == 2 else 0), (what, main)
+                    assert pilot == 2 | (4 if ctr else 0) | (8 if small else 0) | (16 if sweep == 2 else 0), (what, pilot)
+                    seen_main.add(main)
+                    seen_pilot.add(pilot)
+    assert len(seen_main) == 16 and len(seen_pilot) == 8
