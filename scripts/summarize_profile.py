@@ -7,6 +7,8 @@ usage: scripts/summarize_profile.py <tag> <round> [workload_key]"""
 import collections, csv, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import source_sha16          # identifies the sources the profiled binary was built from (bench.py prints the same)
 tag, rnd = sys.argv[1], sys.argv[2]
 key = sys.argv[3] if len(sys.argv) > 3 else None
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
@@ -24,13 +26,14 @@ for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
         if "render_kernel<" not in name:
             continue
         targs = [t.strip() for t in name.split("render_kernel<")[1].split(">")[0].split(",")]    # COUNT, PILOT, CTR, SMALL
-        if targs[1] == "false":                                                                   # skip the PILOT instantiation
+        if targs[1] == "false" and "finalize" not in name:                                        # skip the PILOT instantiation
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         v = sorted(v)
         vals[k] = v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])     # median: the counters are
         launches[k] = len(v)           # device-wide, and a launch now and then picks up a neighbour's traffic (one WRITE_SIZE sample of 6 x the rest)
-out = {"source": f"gpurun_out/prof_{tag} (scripts/profile.sh: separate rocprofv3 --pmc passes); medians over the launches", "per_launch_median": vals,
+out = {"source": f"gpurun_out/prof_{tag} (scripts/profile.sh: separate rocprofv3 --pmc passes); medians over the launches",
+       "source_sha16": source_sha16(), "per_launch_median": vals,
        "launches_averaged": launches}
 if "GRBM_GUI_ACTIVE" in vals:
     cyc = vals["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
@@ -39,6 +42,11 @@ if "GRBM_GUI_ACTIVE" in vals:
         out["derived"]["valu_issue_utilisation_at_2cyc_per_inst"] = vals["SQ_INSTS_VALU"] * 2.0 / (1024 * cyc)
         out["derived"]["valu_note"] = ("per-kernel cycles: launches of consecutive frames overlap, so this under-states the chip's "
                                        "utilisation; over wall time per frame it is SQ_INSTS_VALU*2/(1024*ms_per_step*clock)")
+    for a_, b_ in (("SQ_WAIT_ANY", "wave_cycles_parked_frac"), ("SQ_WAIT_INST_ANY", "wave_cycles_issue_stalled_frac")):
+        if a_ in vals and "SQ_WAVE_CYCLES" in vals:
+            out["derived"][b_] = vals[a_] / vals["SQ_WAVE_CYCLES"]
+    if "SQ_INSTS_SALU" in vals and "SQ_INSTS_VALU" in vals:
+        out["derived"]["salu_per_valu"] = vals["SQ_INSTS_SALU"] / vals["SQ_INSTS_VALU"]
     if "SQ_THREAD_CYCLES_VALU" in vals and "SQ_ACTIVE_INST_VALU" in vals:
         out["derived"]["valu_thread_utilisation"] = vals["SQ_THREAD_CYCLES_VALU"] / (vals["SQ_ACTIVE_INST_VALU"] * 64.0)
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
@@ -72,9 +80,25 @@ if bench_line and "SQ_INSTS_VALU" in vals and key:
     vj[key] = {"issue_frac": out["derived"].get("valu_issue_utilisation_at_2cyc_per_inst"),
                "thread_utilisation": out["derived"].get("valu_thread_utilisation"),
                "valu_insts_per_wave_bounce": out["derived"]["valu_insts_per_wave_bounce"],
-               "source": f"profiles/{rnd}_{tag}_pmc.json"}
+               "source": f"profiles/{rnd}_{tag}_pmc.json", "source_sha16": source_sha16()}
     vj["_note"] = "SQ counters per render_kernel launch from rocprofv3 --pmc passes of bench.py (scripts/profile.sh); bench.py copies them into valu.pmc_*"
     json.dump(vj, open(vj_path, "w"), indent=1, sort_keys=True)
+# the launch timeline of the traced run: consecutive frames' render kernels overlap (two frames in flight)
+tl = os.path.join(src, "trace", "trace_kernel_trace.csv")
+if os.path.exists(tl):
+    rows = [r for r in csv.DictReader(open(tl)) if "render_kernel<" in r["Kernel_Name"] or "finalize_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    if rows:
+        t0 = int(rows[0]["Start_Timestamp"])
+        with open(os.path.join(dst, f"{rnd}_{tag}_launch_timeline.txt"), "w") as f:
+            f.write(f"# rocprofv3 --kernel-trace of `bench.py` ({tag}): start / end of the render and finalize launches, ms since the first one.\n"
+                    "# Two frames are in flight: launch n+1 starts while launch n's last pixels drain, so a launch's own duration is about\n"
+                    "# twice the distance between consecutive ends (= the wall time per step).  ISA resources of the headline instantiation\n"
+                    "# (scripts/kernel_resources.py; rocprofv3 reports granules / dynamic LDS as 0): see profiles/README.md.\n")
+            for r in rows[:40]:
+                nm = "render " + r["Kernel_Name"].split("render_kernel")[1][:34] if "render_kernel" in r["Kernel_Name"] else "finalize"
+                s_, e_ = (int(r["Start_Timestamp"]) - t0) * 1e-6, (int(r["End_Timestamp"]) - t0) * 1e-6
+                f.write(f"{nm:46s} start {s_:9.3f}  end {e_:9.3f}  duration {e_ - s_:8.3f}\n")
 json.dump(out, open(os.path.join(dst, f"{rnd}_{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(out.get("derived", {}), indent=1))
 print(open(os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv")).read())
