@@ -176,8 +176,10 @@ def abi_single_process_leg(a, n, width, height, spp, ref_rgb):
     import tempfile
     import numpy as np
     exe = os.path.join(ROOT, "myraytracer_amd", "lib", "native_runner")
+    # (MRT_BENCH_ABI_DEVICES=0,0 rehearses this leg on a box with fewer GPUs than ranks: the shards then share devices)
+    devs = os.environ.get("MRT_BENCH_ABI_DEVICES")
     common = [exe, "--width", str(width), "--height", str(height), "--samples-per-frame", str(spp), "--ray-depth", str(a.depth),
-              "--seed", "1", "--scene", a.scene, "--gpus", str(n), "--rng", a.rng]
+              "--seed", "1", "--scene", a.scene, "--rng", a.rng] + (["--devices", devs] if devs else ["--gpus", str(n)])
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "frame.pfm")
         r = subprocess.run(common + ["--frames", "1", "--out", out], capture_output=True, text=True, timeout=600)
@@ -554,7 +556,7 @@ def main():
             dist.destroy_process_group()
         except Exception:               # noqa: BLE001
             pass
-    if rank == 0 and use_dist and backend == "nccl" and world > 1 and not a.no_abi_legs:
+    if rank == 0 and use_dist and world > 1 and not a.no_abi_legs and (backend == "nccl" or os.environ.get("MRT_BENCH_ABI_DEVICES")):
         try:
             out["abi_single_process"] = abi_single_process_leg(a, world, width, height, spp,
                                                                ref_np[..., :3].copy().view(np.uint32) if ref_np is not None else None)

@@ -18,7 +18,7 @@ python bench.py --config c2 --no-cpu-baseline --frames-per-step 32 --steps 4 --w
 python bench.py --config interactive --no-cpu-baseline --steps 400 --warmup 40 > $O/bench_interactive.json 2>/dev/null
 python bench.py --config interactive --no-cpu-baseline --frames-per-step 32 --steps 20 --warmup 2 > $O/bench_interactive_x32.json 2>/dev/null
 MRT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --verify > $O/bench_forced_dist.json 2>/dev/null
-MRT_BENCH_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline --verify --steps 2 --warmup 1 > $O/rehearsal_gloo_n2.json 2>/dev/null
+MRT_BENCH_ABI_DEVICES=0,0 MRT_BENCH_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline --verify --steps 2 --warmup 1 > $O/rehearsal_gloo_n2.json 2>/dev/null
 bash scripts/profile.sh c3 --steps 4 --warmup 2 > $O/profile_c3.log 2>&1
 bash scripts/profile.sh c5 --config c5 --steps 2 --warmup 1 > $O/profile_c5.log 2>&1
 python scripts/config_rates.py > $O/config_rates.txt 2>&1
