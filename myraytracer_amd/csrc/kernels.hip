@@ -376,6 +376,7 @@ template <> struct Ent<true>  { typedef uint16_t type; static constexpr uint32_t
 template <> struct Ent<false> { typedef uint32_t type; static constexpr uint32_t id_bits = 26u; };
 
 // LDS of one wave: hit slots, rays, pixel FIFO, work queues, candidate masks
+__host__ __device__ constexpr uint32_t lds_index_bytes(uint32_t n_members) { return (n_members * 2u + 15u) & ~15u; }     // small scenes' u16 sphere indices
 __host__ __device__ constexpr uint32_t lds_off_rays() { return 0u; }                   // 64 x {ox,oy,oz,dx | dy,dz, u64 hit slot}
 __host__ __device__ constexpr uint32_t lds_off_ring() { return 2048u; }                // kRingCap x u32
 __host__ __device__ constexpr uint32_t lds_off_queues() { return 2048u + 512u; }
@@ -452,7 +453,9 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     // small scenes always have one level (api.cpp): the queue bookkeeping below folds to two queues
     constexpr int kLvMax = SMALL ? 1 : (int)kMaxLevels;
     const uint32_t levels = SMALL ? 1u : P.levels;
-    const uint32_t nodes_bytes = SMALL ? P.n_nodes * (uint32_t)sizeof(SphereRec) : 0u;
+    // (small scenes: the member records, then their sphere indices as u16 -- what a root round reads per item; from L2 the
+    // index was a dependent global load in the middle of every root round)
+    const uint32_t nodes_bytes = SMALL ? P.n_nodes * (uint32_t)sizeof(SphereRec) + lds_index_bytes(P.n_members) : 0u;
     unsigned char* const wlds = lds_raw + nodes_bytes + wave * lds_wave_bytes(SMALL, levels, P.gen_cap, P.mask_chunks);
     // lane l's 32 bytes: (ox,oy,oz,dx) (dy,dz) and the u64 slot its closest hit is min-ed into
     float4* const rays = reinterpret_cast<float4*>(wlds + lds_off_rays());
@@ -460,10 +463,13 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     uint32_t* const ring = reinterpret_cast<uint32_t*>(wlds + lds_off_ring());     // FIFO of waiting pixels: tile << 6 | lane-in-tile
     entry_t* const queues = reinterpret_cast<entry_t*>(wlds + lds_off_queues());   // queue k at k * kQueueCap
     uint32_t* const masks = reinterpret_cast<uint32_t*>(wlds + lds_off_masks(SMALL, levels, P.gen_cap)) + lane;   // records 32 w .. 32 w + 31 of the block at masks[w*64]
+    const uint16_t* const index_lds = reinterpret_cast<const uint16_t*>(lds_raw + P.n_nodes * (uint32_t)sizeof(SphereRec));
     if (SMALL) {
         SphereRec* const dst = reinterpret_cast<SphereRec*>(lds_raw);
         const uint32_t n_rec = P.n_nodes;
         for (uint32_t i = threadIdx.x; i < n_rec; i += 64u * kWavesPerGroup) dst[i] = P.nodes[i];
+        uint16_t* const di = reinterpret_cast<uint16_t*>(lds_raw + n_rec * (uint32_t)sizeof(SphereRec));
+        for (uint32_t i = threadIdx.x; i < P.n_members; i += 64u * kWavesPerGroup) di[i] = (uint16_t)P.member_index[i];   // < 1,024 spheres
         __syncthreads();
     }
 
@@ -890,7 +896,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         // index-order scan with `t_sup <= t` (:291-296) ends with (`near` is tried first,
                         // `far` only if `near` is out of range: near >= t_sup implies far >= t_sup).
                         const SphereRec sm = nodes[node];
-                        const uint32_t sidx = member_index[node];
+                        const uint32_t sidx = SMALL ? (uint32_t)index_lds[node] : member_index[node];
                         const float ocx = ro.x - sm.cx, ocy = ro.y - sm.cy, ocz = ro.z - sm.cz;
                         const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
                         const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sm.neg_r2)));
@@ -1375,7 +1381,8 @@ int launch_arith_pairs(const float* d_x, const float* d_y, uint32_t n, uint32_t*
 // SMALL scenes (every node id < 1024): member records live in LDS and work items are u16
 static bool scene_is_small(const KParams& p) { return p.n_members <= 1024u; }
 static uint32_t group_lds_bytes(const KParams& p, bool small) {
-    return (small ? p.n_nodes * (uint32_t)sizeof(SphereRec) : 0u) + kWavesPerGroup * lds_wave_bytes(small, p.levels, p.gen_cap, p.mask_chunks);
+    return (small ? p.n_nodes * (uint32_t)sizeof(SphereRec) + lds_index_bytes(p.n_members) : 0u) +
+           kWavesPerGroup * lds_wave_bytes(small, p.levels, p.gen_cap, p.mask_chunks);
 }
 
 // the persistent render waves (pilot: + its cost-only finalize) on `stream`
