@@ -238,6 +238,13 @@ def main():
     if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or force_dist):
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
 
+    # The contract is ONE JSON line on stdout.  Libraries chat there too (RCCL greets a new communicator with a version banner,
+    # gloo announces its peers), so from here on file descriptor 1 points at stderr and the line goes to a private duplicate of
+    # the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -531,7 +538,7 @@ def main():
         if rank == 0 and out is not None and printed.acquire(blocking=False):
             if extra:
                 out.update(extra)
-            print(json.dumps(out), flush=True)
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if use_dist and backend == "nccl" and not a.no_abi_legs:
         def give_up():
