@@ -182,14 +182,14 @@ def abi_single_process_leg(a, n, width, height, spp, ref_rgb):
               "--seed", "1", "--scene", a.scene, "--rng", a.rng] + (["--devices", devs] if devs else ["--gpus", str(n)])
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "frame.pfm")
-        r = subprocess.run(common + ["--frames", "1", "--out", out], capture_output=True, text=True, timeout=600)
+        r = subprocess.run(common + ["--frames", "1", "--out", out], capture_output=True, text=True, timeout=120)
         if r.returncode != 0:
             raise RuntimeError((r.stderr or r.stdout).strip()[-300:])
         raw = open(out, "rb").read()
         head = f"PF\n{width} {height}\n-1.0\n".encode()
         img = np.frombuffer(raw[len(head):], np.float32).reshape(height, width, 3)
         same = bool(ref_rgb is not None and np.array_equal(img.view(np.uint32), ref_rgb))
-    r = subprocess.run(common + ["--warmup", "1", "--frames", "2"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run(common + ["--warmup", "1", "--frames", "2"], capture_output=True, text=True, timeout=120)
     if r.returncode != 0:
         raise RuntimeError((r.stderr or r.stdout).strip()[-300:])
     rate = float(r.stdout.split("Msamples/s")[0].split()[-1])
@@ -564,11 +564,18 @@ def main():
         except Exception:               # noqa: BLE001
             pass
     if rank == 0 and use_dist and world > 1 and not a.no_abi_legs and (backend == "nccl" or os.environ.get("MRT_BENCH_ABI_DEVICES")):
+        def give_up2():
+            emit({"abi_single_process": {"error": "timed out after 300 s (watchdog); the rest of the line was already final"}})
+            os._exit(0)
+        dog2 = threading.Timer(300.0, give_up2)
+        dog2.daemon = True
+        dog2.start()
         try:
             out["abi_single_process"] = abi_single_process_leg(a, world, width, height, spp,
                                                                ref_np[..., :3].copy().view(np.uint32) if ref_np is not None else None)
         except Exception as e:          # noqa: BLE001
             out["abi_single_process"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog2.cancel()
     emit()
 
 
