@@ -12,6 +12,9 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
         st.debug_set_hierarchy(*[int(x) for x in os.environ["MRT_HIER"].split(",")])
     if os.environ.get("MRT_BOXES"):
         st.debug_set_boxes(os.environ["MRT_BOXES"] == "1")
+    if os.environ.get('MRT_SCHED'):
+        a_ = [int(x) for x in os.environ['MRT_SCHED'].split(',')]
+        st.debug_set_schedule(a_[0], a_[1])
     st.set_world(sp)
     if cam is not None: st.set_camera(cam)
     if os.environ.get("MRT_RNG"): st.set_rng_mode(int(os.environ["MRT_RNG"]))
