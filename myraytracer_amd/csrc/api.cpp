@@ -1174,7 +1174,12 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     if (S.queue_dirty) HIP_TRY(c, hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), S.stream));   // an earlier frame of this slot failed half way
     S.queue_dirty = true;                        // until this frame's last finalize pass has been queued
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], S.stream));
-    int e = mrt::launch_render(p, false, c->n_waves, S.stream, &c->last_launch[0]);
+    // A launch whose pixel chains are a handful of bounces (the reference's default: ONE frame of 1 sample per pixel) is bound
+    // by its longest path -- up to ray_depth wave-iterations in sequence -- not by throughput: with fewer resident waves every
+    // iteration is shorter (1080p, 1 spp: 20 waves per CU 0.74 ms, 8 waves 0.42 ms; DESIGN_HISTORY.md round 3).
+    uint32_t launch_waves = c->n_waves;
+    if (chain_spp < 4u && c->waves_per_cu_override == 0) launch_waves = std::min(launch_waves, c->cus * 8u);
+    int e = mrt::launch_render(p, false, launch_waves, S.stream, &c->last_launch[0]);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], S.stream));
     HIP_TRY(c, hipEventRecord(S.render_done, S.stream));
