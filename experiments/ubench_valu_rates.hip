@@ -51,6 +51,24 @@ KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %2")
 KERNEL(k_fmac_dpp, "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
 KERNEL(k_readlane, "v_readlane_b32 s20, %0, 5")
 
+// packed fp32 (two lanes' worth of math per wave-instruction, operands in VGPR pairs): does a 3-distinct-operand
+// v_pk_fma_f32 cost what a 3-distinct-VGPR v_fma_f32 costs?  (8 independent chains of pairs = 16 results, as above)
+#define KERNEL64(name, ASM)                                                         \
+__global__ void __launch_bounds__(256) name(uint32_t* out, int iters) {             \
+  uint64_t a[8]; uint64_t x = (threadIdx.x * 2654435761ull + 12345ull) | 0x3f8001233f800123ull, y = 0x3f8001233f800456ull; \
+  _Pragma("unroll") for (int i = 0; i < 8; i++) a[i] = x + i * 977ull;              \
+  for (int it = 0; it < iters; it++) {                                              \
+    _Pragma("unroll") for (int r = 0; r < 2; r++)                                   \
+    _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(ASM : "+v"(a[i]) : "v"(x), "v"(y)); \
+  }                                                                                 \
+  uint64_t s = 0; _Pragma("unroll") for (int i = 0; i < 8; i++) s ^= a[i];          \
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(s ^ (s >> 32));           \
+}
+KERNEL64(k_pk_fma, "v_pk_fma_f32 %0, %0, %2, %1")
+KERNEL64(k_pk_fma_2v, "v_pk_fma_f32 %0, %0, %0, %1")
+KERNEL64(k_pk_mul, "v_pk_mul_f32 %0, %0, %2")
+KERNEL64(k_pk_add, "v_pk_add_f32 %0, %0, %2")
+
 template <typename K> void run(const char* name, K k, uint32_t* d, int waves_per_simd) {
   const int iters = 60000, cus = 256;
   dim3 grid(cus * waves_per_simd), block(256);
@@ -67,6 +85,7 @@ int main() {
 #define RUN(k) run(#k, k, d, 4)
   RUN(k_fma); RUN(k_fma_k); RUN(k_fmac); RUN(k_fma_s); RUN(k_fma_2v); RUN(k_cndmask_s); RUN(k_cmp_s); RUN(k_bfe); RUN(k_lshr); RUN(k_min); RUN(k_or); RUN(k_sub_u32); RUN(k_add_f32); RUN(k_mul_f32); RUN(k_sub_f32); RUN(k_and); RUN(k_xor); RUN(k_add_u32); RUN(k_lshl); RUN(k_lshl_add);
   RUN(k_alignbit); RUN(k_cndmask); RUN(k_cmp); RUN(k_cvt); RUN(k_mov); RUN(k_bcnt); RUN(k_mbcnt); RUN(k_mul_lo); RUN(k_sqrt); RUN(k_ffbh);
+  RUN(k_pk_fma); RUN(k_pk_fma_2v); RUN(k_pk_mul); RUN(k_pk_add);      // 16 wave-instructions per iteration, each TWO operations per lane
   run("k_fma", k_fma, d, 2); run("k_and", k_and, d, 2); run("k_fma", k_fma, d, 8); run("k_and", k_and, d, 8);
   return 0;
 }
