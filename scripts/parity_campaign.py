@@ -42,6 +42,8 @@ def main():
     for case in range(first, first + n_cases):
         rng = np.random.default_rng(case)
         n = int(rng.choice([1, 3, 8, 17, 64, 100, 257, 300, 520, 1025, 1100, 1500, 2000, 3000, 5000]))      # (> 1,020: the large-scene layout, with boxes)
+        if os.environ.get('MRT_CAMPAIGN_LARGE'):        # only scenes that walk boxes
+            n = int(rng.choice([1021, 1100, 1500, 2000, 3000, 4100, 5000, 8000]))
         sc, scale, off = scene(rng, n)
         if rng.random() < 0.25:
             cam = None
