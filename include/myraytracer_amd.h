@@ -274,7 +274,8 @@ int mrt_debug_read_pixel_costs(mrt_ctx* ctx, uint32_t* out, size_t cap);
  * is no longer used); takes effect at the next mrt_set_world* call. */
 int mrt_debug_set_cluster_factor(mrt_ctx* ctx, float factor);
 /* Diagnostic / tuning: depth of the bounding-sphere hierarchy built by the next mrt_set_world* call:
- * levels are added (up to max_levels, 1..4) while the top level has more than top_target records. */
+ * levels are added (up to max_levels, 1..4) while the top level has more than top_target records (0 = automatic: 256, or
+ * 128 for scenes beyond 4,096 member slots, whose walk tests boxes below the top). */
 int mrt_debug_set_hierarchy(mrt_ctx* ctx, uint32_t max_levels, uint32_t top_target);
 /* Diagnostic / tuning: which variant of the conservative sweep runs: 0 = automatic (matrix cores where the
  * expanded test's slack is negligible for the scene and camera), 1 = SGPR-fed VALU sweep, 2 = matrix cores.
@@ -335,8 +336,9 @@ int mrt_debug_arith_pairs(mrt_ctx* ctx, const float* x, const float* y, size_t n
  * (tests/test_gpu_parity.py::test_every_render_kernel_instantiation_against_the_oracle). */
 int mrt_debug_last_launch(mrt_ctx* ctx, uint32_t out[2]);
 /* Diagnostic A/B switch (large scenes, > 1,024 member slots): 0 makes the walk test only the bounding spheres, as small
- * scenes do; 1 (default) also the axis-aligned boxes of the hierarchy's nodes.  Either way the image is the same. */
-int mrt_debug_set_boxes(mrt_ctx* ctx, int enabled);
+ * scenes do; 1 (default) also the axis-aligned boxes of the hierarchy's nodes where that pays (beyond 4,096 member slots);
+ * 2 wherever the layout allows (every large scene).  Either way the image is the same. */
+int mrt_debug_set_boxes(mrt_ctx* ctx, int mode);
 /* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
 int mrt_debug_sweep_variant(mrt_ctx* ctx);
 /* Diagnostic A/B switch: 0 makes mrt_render launch every frame on its own; 1 = automatic (default); 2 / 3 force the form a

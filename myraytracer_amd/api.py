@@ -406,9 +406,10 @@ class State:
         """Before the first redraw: samples per pixel of the pilot launch, persistent waves per CU (0 = automatic)."""
         self._check(self._L.mrt_debug_set_schedule(self._ctx, pilot_spp, waves_per_cu), "mrt_debug_set_schedule")
 
-    def debug_set_boxes(self, enabled: bool):
-        """A/B switch (large scenes): False = the walk tests bounding spheres only; the image is the same."""
-        self._check(self._L.mrt_debug_set_boxes(self._ctx, int(enabled)), "mrt_debug_set_boxes")
+    def debug_set_boxes(self, mode):
+        """A/B switch (large scenes): 0 / False = the walk tests bounding spheres only, 1 = automatic (boxes beyond 4,096
+        member slots), 2 / True = boxes for every large scene; the image is the same."""
+        self._check(self._L.mrt_debug_set_boxes(self._ctx, 2 if mode is True else int(mode)), "mrt_debug_set_boxes")
 
     def debug_arith(self, mode: int, bits_range: Sequence[int], count: int = 0, seed: int = 1):
         """mrt_debug_arith: (tested, mismatches, smallest mismatching operand) of the kernel's unscaled sqrt (mode 0, every

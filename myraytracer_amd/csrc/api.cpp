@@ -425,6 +425,7 @@ void build_boxes(const float* centers4, const float* radii, const std::vector<mr
     }
 }
 
+constexpr uint32_t kBoxMinMembers = 4096;     // member slots from which the walk tests boxes by default (fill_scene_params)
 void build_hierarchy(const float* centers4, const float* radii, uint32_t n, float factor, uint32_t max_levels,
                      uint32_t top_target, Hierarchy& H) {
     const mrt::SphereRec never{0.0f, 0.0f, 0.0f, INFINITY};
@@ -454,6 +455,10 @@ void build_hierarchy(const float* centers4, const float* radii, uint32_t n, floa
     // scenes whose members fit 10-bit ids (the kernel's SMALL variant) keep one level: with <= 256 clusters
     // the sweep is cheap and the bounds of 16 spheres are loose (C3: a ray touches 10 of 38 such bounds)
     if (H.n_members <= 1024u) max_levels = 1;      // (same test as scene_is_small() in kernels.hip)
+    // top_target 0 = automatic: levels are added while the top has more than 256 records -- 128 where the walk tests boxes
+    // below the top, which make a smaller top cheaper (round 3: 4,901 spheres 34.1 -> 33.3 ms per 64-spp frame, 10,001 spheres
+    // 48.2 -> 47.3; without boxes 1,297 / 2,501 spheres lose 20 % with a top of <= 64)
+    if (top_target == 0) top_target = H.n_members > kBoxMinMembers ? 128u : 256u;
     while (H.levels < max_levels && cur.size() > top_target) {
         const size_t span = (size_t)1 << (2 * (H.levels + 1));        // members under one node of the new level
         const size_t n_par = (cur.size() + 3) / 4;
@@ -1076,7 +1081,10 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     p.boxes = c->d_boxes;
     for (uint32_t k = 0; k <= mrt::kMaxLevels; k++) p.box_base[k] = c->box_base[k];
     p.box_top = c->box_base[c->levels];
-    p.use_boxes = (c->boxes_enabled && c->n_members > 1024u) ? 1u : 0u;     // large scenes only (kernels.hip: !SMALL)
+    // large scenes only (kernels.hip: !SMALL), and by default only beyond kBoxMinMembers member slots: below, a filter round
+    // costs what it saves (1,297 / 2,501 spheres: 17.0 / 23.0 ms per 64-spp frame without boxes, 17.6 / 23.5 with; 4,901 /
+    // 10,001: 38.6 / 57.2 without, 33.3 / 47.3 with)
+    p.use_boxes = (c->n_members > 1024u && (c->boxes_mode == 2 || (c->boxes_mode == 1 && c->n_members > kBoxMinMembers))) ? 1u : 0u;
     p.box_quad = c->box_quad ? 1u : 0u;
     p.n_direct = c->n_direct; p.direct_first = c->direct_first;
     for (uint32_t k = 0; k < mrt::kMaxDirect; k++) { p.direct[k] = c->direct[k]; p.direct_index[k] = c->direct_index[k]; }
@@ -1290,7 +1298,7 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
                               float* top_out, size_t top_cap, float* nodes_out, size_t nodes_cap,
                               uint32_t* member_index_out, size_t member_cap, uint16_t* mfma_out, size_t mfma_cap,
                               float mfma_origin_out[3], uint32_t info[10]) {
-    if ((!spheres && n) || !info || max_levels < 1 || max_levels > mrt::kMaxLevels || top_target < 1 || n > mrt::kMaxSpheres)
+    if ((!spheres && n) || !info || max_levels < 1 || max_levels > mrt::kMaxLevels || n > mrt::kMaxSpheres)
         return MRT_ERR_INVALID_ARG;
     std::vector<float> centers(4 * (n ? n : 1)), radii(n ? n : 1);
     for (size_t i = 0; i < n; i++) {
@@ -1321,7 +1329,7 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
 
 int mrt_debug_build_boxes(const mrt_sphere* spheres, size_t n, uint32_t max_levels, uint32_t top_target, float* boxes_out,
                           size_t boxes_cap, uint32_t info[8]) {
-    if ((!spheres && n) || !info || max_levels < 1 || max_levels > mrt::kMaxLevels || top_target < 1 || n > mrt::kMaxSpheres)
+    if ((!spheres && n) || !info || max_levels < 1 || max_levels > mrt::kMaxLevels || n > mrt::kMaxSpheres)
         return MRT_ERR_INVALID_ARG;
     std::vector<float> centers(4 * (n ? n : 1)), radii(n ? n : 1);
     for (size_t i = 0; i < n; i++) {
@@ -1402,9 +1410,9 @@ int mrt_debug_last_launch(mrt_ctx* c, uint32_t out[2]) {
     return MRT_OK;
 }
 
-int mrt_debug_set_boxes(mrt_ctx* c, int enabled) {
-    if (!c) return MRT_ERR_INVALID_ARG;
-    c->boxes_enabled = enabled != 0;
+int mrt_debug_set_boxes(mrt_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return MRT_ERR_INVALID_ARG;
+    c->boxes_mode = mode;
     return MRT_OK;
 }
 
@@ -1420,7 +1428,7 @@ int mrt_debug_mfma_scale(double reach, float scale_out[4], uint32_t* neg_k2_bf16
 }
 
 int mrt_debug_set_hierarchy(mrt_ctx* c, uint32_t max_levels, uint32_t top_target) {
-    if (!c || max_levels < 1 || max_levels > mrt::kMaxLevels || top_target < 1) return MRT_ERR_INVALID_ARG;
+    if (!c || max_levels < 1 || max_levels > mrt::kMaxLevels) return MRT_ERR_INVALID_ARG;      // top_target 0 = automatic
     c->max_levels = max_levels;
     c->top_target = top_target;
     return MRT_OK;

@@ -36,11 +36,12 @@ struct mrt_ctx {
     uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
     mrt::BoxRec* d_boxes = nullptr;        // axis-aligned boxes of the nodes of levels 1 .. top (large scenes' walk)
     uint32_t box_base[mrt::kMaxLevels + 1] = {0, 0, 0, 0, 0};
-    bool box_quad = false, boxes_enabled = true;
+    bool box_quad = false;
+    int boxes_mode = 1;                    // mrt_debug_set_boxes: 0 never, 1 automatic (beyond 4,096 member slots), 2 whenever the layout allows
     float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
-    // hierarchy depth rule (build_hierarchy): levels are added while the top has more than top_target records.  64 since the
-    // walk tests boxes below the top (round 3: C5 at 512 spp 2,800 Msamples/s with 160 top records, 2,940 with 40; 256 before)
-    uint32_t max_levels = mrt::kMaxLevels, top_target = 64;
+    // hierarchy depth rule (build_hierarchy): levels are added while the top has more than top_target records; 0 = automatic
+    // (256, or 128 for scenes whose walk tests boxes)
+    uint32_t max_levels = mrt::kMaxLevels, top_target = 0;
     uint32_t levels = 1, n_nodes = 0, n_members = 0;
     uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
     uint32_t n_direct = 0, direct_first = 0;

@@ -69,7 +69,7 @@ def main():
         with M.State(M.Args(w, h, spp, depth, 1.0), seed=seed) as st:
             st.debug_set_hierarchy(*hier)
             st.debug_set_sweep(int(rng.integers(0, 3)))      # automatic / VALU / matrix-core sweep
-            st.debug_set_boxes(bool(rng.random() < 0.8))     # round 3: the walk's box tests (large scenes), mostly on
+            st.debug_set_boxes([True, True, True, False, 1][int(rng.integers(0, 5))])     # round 3: the walk's box tests: forced on, off, or automatic (beyond 4,096 member slots)
             st.debug_set_frame_batching(int(rng.choice([1, 1, 2, 3])))     # automatic / frames in the lane / frames as queue layers
             count = bool(rng.random() < 0.7)
             st.set_draw_counting(count)

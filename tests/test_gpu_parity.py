@@ -170,6 +170,7 @@ def test_every_render_kernel_instantiation_against_the_oracle(mrt, oracle):
                     with mrt.State(mrt.Args(w, h, spp, depth), seed=12) as st:
                         st.debug_set_schedule(2, 1)                 # 1 wave per CU: fewer waves than the 408 tiles
                         st.debug_set_sweep(sweep)
+                        st.debug_set_boxes(True)                    # (by default only scenes beyond 4,096 member slots walk boxes)
                         st.set_world(sc)
                         st.set_camera(cam)
                         st.set_rng_mode(ctr)
