@@ -12,8 +12,8 @@ CLI      := $(LIBDIR)/native_runner
 # -mllvm -amdgpu-mfma-vgpr-form: the matrix-core sweep reads its MFMA results with VALU ops; in AGPRs
 # every value would cost a v_accvgpr_read first.
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-vectorize -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wall -Wextra -Wno-unused-parameter
-SRCS     := $(CSRC)/kernels.hip $(CSRC)/tile_order.hip $(CSRC)/api.cpp $(CSRC)/multi_gpu.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
-HDRS     := $(CSRC)/mrt_internal.h $(CSRC)/mrt_ctx.h include/myraytracer_amd.h
+SRCS     := $(CSRC)/kernels.hip $(CSRC)/tile_order.hip $(CSRC)/debug_kernels.hip $(CSRC)/api.cpp $(CSRC)/multi_gpu.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
+HDRS     := $(CSRC)/mrt_internal.h $(CSRC)/mrt_ctx.h $(CSRC)/mrt_device.h include/myraytracer_amd.h include/myraytracer_amd_debug.h
 
 all: $(LIB) $(CLI) oracle
 
@@ -31,9 +31,14 @@ $(OBJDIR)/isa.ok: $(CSRC)/kernels.hip $(HDRS) scripts/check_isa.py
 	python3 scripts/check_isa.py
 	@touch $@
 
-$(LIB): $(OBJS) $(OBJDIR)/isa.ok
+# mrt_build_id(): the sha256 over the sources (scripts/source_hash.py), regenerated whenever one of them changes
+$(OBJDIR)/build_id.cpp: $(SRCS) $(HDRS) Makefile scripts/source_hash.py
+	@mkdir -p $(OBJDIR)
+	python3 scripts/source_hash.py --cpp > $@
+
+$(LIB): $(OBJS) $(OBJDIR)/isa.ok $(OBJDIR)/build_id.cpp
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS) -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -shared -o $@ $(OBJS) $(OBJDIR)/build_id.cpp -ldl
 
 $(CLI): $(CSRC)/native_runner.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -o $@ $(CSRC)/native_runner.cpp -L$(LIBDIR) -lmyraytracer_amd -Wl,-rpath,'$$ORIGIN'
@@ -48,6 +53,6 @@ clean:
 .PHONY: all oracle clean
 
 # diagnostic build with s_memtime phase stamps (scripts/phase_profile.py); not the product
-stamps: $(SRCS) $(HDRS)
+stamps: $(SRCS) $(HDRS) $(OBJDIR)/build_id.cpp
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $(LIBDIR)/libmyraytracer_amd_stamps.so $(SRCS) -ldl
+	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $(LIBDIR)/libmyraytracer_amd_stamps.so $(SRCS) $(OBJDIR)/build_id.cpp -ldl

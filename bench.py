@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+HANG_EXIT_CODE = 75       # a watchdog ended a hung N > 1 leg: the JSON line is complete and records the hang
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz: fp32 VALU lane-ops/s
 VALU_PER_BOUND_TEST = {1: 11, 2: 2}   # sweep variant 1: 10 fp32 VALU + 1 v_alignbit from SGPRs; 2: 1 fma + 1 v_alignbit after the matrix cores
@@ -106,20 +107,14 @@ def cpu_baseline(spheres, cam, width, height, depth, seed, budget_s=15.0):
 
 
 def source_sha16():
-    """sha256 over the sources the render path is built from: identifies the binary a profile under profiles/ describes
-    (the GPU box has no .git; scripts/summarize_profile.py stores the same value next to the counters)."""
-    import hashlib
-    h = hashlib.sha256()
-    for rel in ("myraytracer_amd/csrc/kernels.hip", "myraytracer_amd/csrc/tile_order.hip", "myraytracer_amd/csrc/api.cpp",
-                "myraytracer_amd/csrc/mrt_internal.h", "myraytracer_amd/csrc/mrt_ctx.h", "Makefile"):
-        try:
-            h.update(open(os.path.join(ROOT, rel), "rb").read())
-        except OSError:
-            h.update(b"?")
-    return h.hexdigest()[:16]
+    """sha256 over the sources the library is built from (scripts/source_hash.py, the one definition the Makefile bakes into
+    the .so as mrt_build_id() and scripts/summarize_profile.py stores next to the counters).  The GPU box has no .git."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from source_hash import source_sha16 as f
+    return f(ROOT)
 
 
-def abi_rccl_leg(st, dist, world, rank, steps, fence, ref_bits):
+def abi_rccl_leg(st, dist, world, rank, steps, fence, ref_bits, in_flight):
     """N > 1, after all timing, NON-FATAL: the C ABI's own gather -- mrt_gather_rccl: grouped ncclSend / ncclRecv straight to
     the root on an ncclComm_t this caller creates with the process's librccl (torch's), then the un-permute -- instead of
     torch.distributed.gather: one verified frame, then `steps` timed redraw + gather steps.  Returns the report (rank 0) / None."""
@@ -132,6 +127,7 @@ def abi_rccl_leg(st, dist, world, rank, steps, fence, ref_bits):
     class UniqueId(C.Structure):
         _fields_ = [("internal", C.c_char * 128)]
     uid = UniqueId()
+    in_flight["call"] = "ncclGetUniqueId / broadcast of the id"
     if rank == 0:
         rc = rccl.ncclGetUniqueId(C.byref(uid))
         if rc:
@@ -141,10 +137,12 @@ def abi_rccl_leg(st, dist, world, rank, steps, fence, ref_bits):
     C.memmove(C.byref(uid), box[0], 128)
     comm = C.c_void_p()
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    in_flight["call"] = "ncclCommInitRank"
     rc = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
     if rc:
         raise RuntimeError(f"ncclCommInitRank -> {rc}")
     try:
+        in_flight["call"] = "mrt_gather_rccl (grouped ncclSend / ncclRecv to rank 0), first frame"
         st.reset()
         fence()
         st.redraw()
@@ -155,6 +153,7 @@ def abi_rccl_leg(st, dist, world, rank, steps, fence, ref_bits):
             import numpy as np
             verified = bool(np.array_equal(st.read_gathered().view(np.uint32), ref_bits))
         fence()
+        in_flight["call"] = "mrt_gather_rccl, timed steps"
         t0 = time.perf_counter()
         for _ in range(steps):
             st.redraw()
@@ -162,6 +161,7 @@ def abi_rccl_leg(st, dist, world, rank, steps, fence, ref_bits):
         fence()
         dt = time.perf_counter() - t0
     finally:
+        in_flight["call"] = "ncclCommDestroy"
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
     return {"verified": verified, "ms_per_step": dt / max(1, steps) * 1e3, "steps": steps, "librccl": path,
@@ -411,8 +411,15 @@ def main():
     # which ranks RCCL actually connected: every rank reports its device; the root checks the communicator's size
     rank_devices = [None] * world
     if use_dist:
+        # ... with its own share of the timed run, so that an imbalance is diagnosable from this one line
+        my_hits, my_slots = c1["world_hit_calls"] - c0["world_hit_calls"], c1["lane_slots"] - c0["lane_slots"]
         dist.all_gather_object(rank_devices, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(device),
-                                              "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None)})
+                                              "pci_bus_id": getattr(torch.cuda.get_device_properties(device), "pci_bus_id", None),
+                                              "ms_per_step": elapsed / max(1, a.steps) * 1e3,
+                                              "render_only_ms_per_step": (elapsed_render_only or 0.0) / max(1, a.steps) * 1e3,
+                                              "kernel_ms": sum(kernel_ms) / max(1, len(kernel_ms)),
+                                              "lane_utilisation": my_hits / my_slots if my_slots else None,
+                                              "world_hit_calls": my_hits})
     else:
         rank_devices = [{"rank": 0, "local_rank": local_rank, "device": torch.cuda.get_device_name(device)}]
 
@@ -442,11 +449,25 @@ def main():
         # (roofline.kernel_ms) exceeds the wall time per step; the VALU fractions use the wall time
         kernel_s = elapsed_max / max(1, a.steps)
         src_now = source_sha16()
+        from myraytracer_amd import _lib as mlib
+        lib_build_id = mlib.load().mrt_build_id().decode()
+        lib_override = os.environ.get("MRT_LIB_OVERRIDE")
+        # a headline needs the product binary built from the sources on disk: not a substituted library, not a stale build
+        binary_ok = lib_build_id == src_now and not lib_override
+        if headline and not binary_ok:
+            sys.exit(f"bench.py: refusing a headline line from this binary: lib_build_id {lib_build_id} (of {mlib.LIB_PATH}) vs sources "
+                     f"{src_now}, MRT_LIB_OVERRIDE={lib_override!r}; rebuild with `make`, or pass --width/--height/--spp for a custom run")
         label = "custom" if (a.width or a.height or a.spp) else a.config.upper()
         if a.rng == "counter":
             label += " (counter-RNG extension)"
         if a.frames_per_step != 1:
             label += f" ({a.frames_per_step} frames per step through mrt_render)"
+        # a pixel is ONE sequential chain in the reference's RNG semantics: a rank with fewer than ~2 pixels per lane the chip
+        # can hold (256 CUs x <= 20 waves x 64 lanes) is bound by its longest chains, not by throughput
+        resident_lanes = 256 * 20 * 64
+        if a.rng == "stream" and local_px < 2 * resident_lanes and spp >= 64:
+            label += (f" [pixel-starved stream shards: {int(local_px)} pixels per rank for {resident_lanes} resident lanes, "
+                      f"one sequential {spp}-sample chain per pixel]")
         prof_src = (pmc or {}).get("source_sha16")
         scene_names = {"cover-glass": "RTIOW cover scene with Dielectric + defocus blur", "cover": "RTIOW cover scene (Lambertian + Metal)",
                        "stress": "10k-sphere stress scene (100 x 100 jittered grid + ground, 80/15/5 % L/M/D)",
@@ -462,7 +483,8 @@ def main():
                        "headline": headline, "sharding": f"interleaved 8-row bands over {world} GPU(s)",
                        "rng": {"stream": "one Xoshiro128+ stream per pixel per frame (the reference's, shader.wgsl:377-382)",
                                "counter": "per-sample hashed states, blocks of 64 samples (extension)"}[a.rng]},
-            "source_sha16": src_now,
+            "source_sha16": src_now, "lib_build_id": lib_build_id, "lib_path": os.path.relpath(mlib.LIB_PATH, ROOT),
+            "lib_matches_sources": binary_ok,
             "rccl_world_size": dist.get_world_size() if use_dist else 1, "backend": backend if use_dist else None,
             "ranks": rank_devices,
             "scene_upload_ms": st.last_set_world_ms(),
@@ -529,10 +551,16 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
 
     # ---- N > 1: the C ABI's own gathers on the same workload, after everything that is timed for `value`.  Non-fatal by
-    # construction: any exception becomes {"error": ...}; a hang (a collective that never completes) is ended by a watchdog
-    # that prints the line already computed and exits 0 -- the measured curve never depends on these legs.
+    # construction: any exception becomes {"error": ...}.  A HANG (a collective or a peer copy that never completes -- these
+    # legs have never run between two physical GPUs) is ended by a watchdog on EVERY rank: rank 0 first prints the line it
+    # already holds -- `value` is final at this point -- with the hang recorded in it ("hang": which call was in flight), every
+    # rank names the call on stderr, and all exit with HANG_EXIT_CODE.  The same watchdog covers the final barrier /
+    # destroy_process_group, where a rank that died in a leg would otherwise leave the others waiting for RCCL's own timeout.
+    # Exit status: 0 whenever the JSON line carries a measured `value` and nothing hung; HANG_EXIT_CODE (75) after a hang -- the
+    # line is still complete and says so -- so that a hang is never recorded as a clean run; other non-zero codes: no line.
     import threading
     printed = threading.Lock()
+    in_flight = {"call": None}
 
     def emit(extra=None):
         if rank == 0 and out is not None and printed.acquire(blocking=False):
@@ -540,44 +568,52 @@ def main():
                 out.update(extra)
             os.write(json_fd, (json.dumps(out) + "\n").encode())
 
-    if use_dist and backend == "nccl" and not a.no_abi_legs:
+    def watchdog(seconds, leg):
         def give_up():
-            emit({"abi_rccl_gather": {"error": "timed out after 240 s (watchdog); the line above it was already final"}})
-            os._exit(0)
-        dog = threading.Timer(240.0, give_up)
-        dog.daemon = True
-        dog.start()
+            msg = f"bench.py rank {rank}: watchdog after {seconds:.0f} s in {leg}; call in flight: {in_flight['call']}"
+            os.write(2, (msg + "\n").encode())
+            emit({leg: {"error": f"timed out after {seconds:.0f} s (watchdog); `value` above was already final"},
+                  "hang": {"leg": leg, "call_in_flight": in_flight["call"], "rank": rank, "exit_code": HANG_EXIT_CODE}})
+            os._exit(HANG_EXIT_CODE)
+        t = threading.Timer(seconds, give_up)
+        t.daemon = True
+        t.start()
+        return t
+
+    if use_dist and backend == "nccl" and not a.no_abi_legs:
+        dog = watchdog(240.0, "abi_rccl_gather")
         leg = None
         try:
             leg = abi_rccl_leg(st, dist, world, rank, min(a.steps, 5), fence,
-                               ref_np.view(np.uint32) if ref_np is not None else None)
+                               ref_np.view(np.uint32) if ref_np is not None else None, in_flight)
         except Exception as e:          # noqa: BLE001 -- non-fatal by design
-            leg = {"error": f"{type(e).__name__}: {e}"[:300]}
+            leg = {"error": f"{type(e).__name__}: {e}"[:300], "call_in_flight": in_flight["call"]}
         dog.cancel()
         if rank == 0:
             out["abi_rccl_gather"] = leg
     st.close()
     if use_dist:
+        dog = watchdog(120.0, "teardown")
         try:
+            in_flight["call"] = "dist.barrier"
             dist.barrier()
+            in_flight["call"] = "dist.destroy_process_group"
             dist.destroy_process_group()
         except Exception:               # noqa: BLE001
             pass
+        dog.cancel()
     if rank == 0 and use_dist and world > 1 and not a.no_abi_legs and (backend == "nccl" or os.environ.get("MRT_BENCH_ABI_DEVICES")):
-        def give_up2():
-            emit({"abi_single_process": {"error": "timed out after 300 s (watchdog); the rest of the line was already final"}})
-            os._exit(0)
-        dog2 = threading.Timer(300.0, give_up2)
-        dog2.daemon = True
-        dog2.start()
+        dog2 = watchdog(300.0, "abi_single_process")
         try:
+            in_flight["call"] = "native_runner --gpus N (mrt_gather: hipMemcpyPeerAsync per band)"
             out["abi_single_process"] = abi_single_process_leg(a, world, width, height, spp,
                                                                ref_np[..., :3].copy().view(np.uint32) if ref_np is not None else None)
         except Exception as e:          # noqa: BLE001
             out["abi_single_process"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         dog2.cancel()
     emit()
-
+    if rank == 0 and out is None:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

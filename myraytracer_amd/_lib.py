@@ -12,8 +12,8 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRT_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libmyraytracer_amd.so")
 
-# every symbol include/myraytracer_amd.h declares (tests/test_abi.py checks this list
-# against the header and against the loaded library)
+# every symbol include/myraytracer_amd.h (the boundary) and include/myraytracer_amd_debug.h (diagnostics, mrt_debug_*)
+# declare (tests/test_abi.py checks this list against both headers and against the loaded library)
 EXPORTS = [
     "mrt_args_default", "mrt_args_resolve_size", "mrt_create", "mrt_destroy", "mrt_set_shard",
     "mrt_set_stream", "mrt_set_world_raw", "mrt_set_world", "mrt_pack_world", "mrt_set_camera",
@@ -22,10 +22,10 @@ EXPORTS = [
     "mrt_frames_done", "mrt_frame_weight", "mrt_frame_shuffle", "mrt_pixel_seed", "mrt_shard_info",
     "mrt_framebuffer_device_ptr", "mrt_read_framebuffer", "mrt_read_counters", "mrt_last_kernel_ms",
     "mrt_kernel_ms_history", "mrt_debug_read_counters", "mrt_debug_wave_log", "mrt_debug_set_tile_sort", "mrt_debug_set_cluster_factor", "mrt_debug_set_hierarchy", "mrt_debug_set_sweep", "mrt_debug_sweep_variant", "mrt_debug_build_hierarchy", "mrt_debug_read_pixel_costs", "mrt_debug_set_schedule", "mrt_debug_mfma_scale",
-    "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_scene_default", "mrt_scene_cover",
+    "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_build_id", "mrt_scene_default", "mrt_scene_cover",
     "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
     "mrt_srgb8", "mrt_write_png", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
-    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit", "mrt_debug_set_frame_batching", "mrt_debug_set_gather_per_band", "mrt_debug_arith", "mrt_debug_arith_pairs", "mrt_debug_set_boxes", "mrt_debug_build_boxes", "mrt_set_draw_counting", "mrt_debug_last_launch",
+    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit", "mrt_debug_set_frame_batching", "mrt_debug_set_gather_per_band", "mrt_debug_arith", "mrt_debug_arith_pairs", "mrt_debug_set_boxes", "mrt_debug_build_boxes", "mrt_set_draw_counting", "mrt_debug_last_launch", "mrt_debug_set_frames_in_flight",
 ]
 
 
@@ -88,12 +88,56 @@ class MrtCounters(C.Structure):
 _lib = None
 
 
+def _soname(path):
+    """DT_SONAME of a 64-bit little-endian ELF shared object (None if it cannot be read)."""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            head = f.read(64)
+            if head[:5] != b"\x7fELF\x02" or head[5] != 1:
+                return None
+            shoff, = struct.unpack_from("<Q", head, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", head, 0x3A)
+            f.seek(shoff)
+            raw = f.read(shentsize * shnum)
+            secs = [struct.unpack_from("<IIQQQQIIQQ", raw, i * shentsize) for i in range(shnum)]
+            for sec in secs:
+                if sec[1] != 6:                             # SHT_DYNAMIC
+                    continue
+                strtab = secs[sec[6]]                       # sh_link -> .dynstr
+                f.seek(sec[4])
+                dyn = f.read(sec[5])
+                for off in range(0, len(dyn) - 15, 16):
+                    tag, val = struct.unpack_from("<qQ", dyn, off)
+                    if tag == 14:                           # DT_SONAME
+                        f.seek(strtab[4] + val)
+                        name = f.read(256)
+                        return name[:name.index(b"\0")].decode()
+                    if tag == 0:
+                        break
+    except (OSError, struct.error, ValueError, IndexError):
+        pass
+    return None
+
+
+def _needed_hip_soname():
+    """The libamdhip64 soname our library was linked against (DT_NEEDED), e.g. libamdhip64.so.7."""
+    import re
+    try:
+        m = re.search(rb"libamdhip64\.so\.\d+", open(LIB_PATH, "rb").read())
+        return m.group(0).decode() if m else None
+    except OSError:
+        return None
+
+
 def _one_hip_runtime():
     """A process must run ONE HIP / HSA runtime.  PyTorch-ROCm bundles its own (torch/lib/libamdhip64.so, the same soname as
     /opt/rocm's): whichever copy is loaded first serves both torch and this library, and when /opt/rocm's comes first torch's
     other bundled libraries still bring their own HSA runtime along -- torch then reports "No HIP GPUs are available".  So if
-    torch is installed but not imported yet, its runtime is loaded here, before ours resolves libamdhip64.so.7; the import
-    order of torch and this package then does not matter.  MRT_HIP_RUNTIME=system skips this (a process without torch)."""
+    torch is installed but not imported yet, its runtime is loaded here, before ours resolves its libamdhip64 -- but only if the
+    bundled library's DT_SONAME is the one ours needs (a torch wheel of another ROCm major would otherwise put two runtimes,
+    or interposed symbols of the wrong one, into the process: the very failure this is meant to prevent); a skipped preload is
+    reported on stderr when MRT_VERBOSE is set.  MRT_HIP_RUNTIME=system skips this (a process without torch)."""
     if os.environ.get("MRT_HIP_RUNTIME") == "system" or "torch" in sys.modules:
         return
     try:
@@ -103,11 +147,19 @@ def _one_hip_runtime():
     if spec is None or not spec.submodule_search_locations:
         return
     hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(hip):
+    if not os.path.exists(hip):
+        return
+    have, need = _soname(os.path.realpath(hip)), _needed_hip_soname()
+    why = None
+    if have is None or need is None or have != need:
+        why = f"its soname {have!r} is not the {need!r} {LIB_PATH} was linked against"
+    else:
         try:
             C.CDLL(hip, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+        except OSError as e:
+            why = str(e)
+    if why and os.environ.get("MRT_VERBOSE"):
+        print(f"myraytracer_amd: torch's bundled {hip} not preloaded: {why}", file=sys.stderr)
 
 
 def load():
@@ -170,6 +222,7 @@ def load():
         "mrt_last_error": (C.c_char_p, [vp]),
         "mrt_status_string": (C.c_char_p, [i32]),
         "mrt_abi_version": (i32, []),
+        "mrt_build_id": (C.c_char_p, []),
         "mrt_scene_default": (i32, [vp, sz]),
         "mrt_scene_cover": (i32, [u64, i32, vp, sz, P(MrtCamera)]),
         "mrt_scene_stress": (i32, [u64, u32, vp, sz, P(MrtCamera)]),
@@ -196,6 +249,7 @@ def load():
         "mrt_debug_build_boxes": (i32, [vp, sz, u32, u32, vp, sz, vp]),
         "mrt_set_draw_counting": (i32, [vp, i32]),
         "mrt_debug_last_launch": (i32, [vp, P(u32)]),
+        "mrt_debug_set_frames_in_flight": (i32, [vp, i32]),
     }
     assert sorted(sig) == sorted(EXPORTS)
     for name, (res, args) in sig.items():

@@ -107,11 +107,14 @@ int alloc_frame_buffers(mrt_ctx* c) {
         HIP_TRY(c, hipMalloc(&S.d_tile_order, (size_t)(c->n_tiles ? c->n_tiles : 1) * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc(&S.d_sort_scratch, (1024 + 16) * sizeof(uint32_t)));
         HIP_TRY(c, hipMemsetAsync(S.d_sort_scratch, 0, (1024 + 16) * sizeof(uint32_t), c->stream));   // [1024] = the tile queue's counter
+        S.pix_acc_layers = 0; S.cost_first_layer = 0; S.cost_layers = 1;
+        S.cost_valid = false;
+        if (&S - c->slot >= 2) continue;        // further slots (pixel-starved shards only) get their colour sums on first use
         HIP_TRY(c, hipMalloc(&S.d_pix_acc, (n ? n : 1) * 16));
         HIP_TRY(c, hipMemsetAsync(S.d_pix_acc, 0, (n ? n : 1) * 16, c->stream));
-        S.pix_acc_layers = 1; S.cost_first_layer = 0; S.cost_layers = 1;
-        S.cost_valid = false;
+        S.pix_acc_layers = 1;
     }
+    c->frame_slots = 2;
     c->inputs_dirty = true;
     // as many persistent single-wave workgroups as the chip holds
     {
@@ -1114,7 +1117,16 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     p.wave_log = c->d_wave_log;
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
     p.pilot_spp = c->pilot_spp;
-    mrt_ctx::FrameSlot& S = c->slot[c->frame_seq % mrt_ctx::kFrameSlots];
+    // how many frames may be in flight from here on (mrt_ctx::kMaxFrameSlots); a change waits for the frames under way
+    {
+        const uint32_t want = c->frame_slots_override > 0 ? (uint32_t)c->frame_slots_override : 2u;
+        if (want != c->frame_slots) {
+            HIP_TRY(c, sync_all(c));
+            c->frame_slots = want;
+        }
+    }
+    c->last_slot = (uint32_t)(c->frame_seq % c->frame_slots);
+    mrt_ctx::FrameSlot& S = c->slot[c->last_slot];
     p.tile_queue = S.d_sort_scratch + 1024;
     p.tile_order = nullptr;
     p.tile_cost = S.d_tile_cost;
@@ -1160,6 +1172,9 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     }
     HIP_TRY(c, hipStreamWaitEvent(S.stream, c->ev_inputs, 0));
     HIP_TRY(c, hipStreamWaitEvent(S.stream, S.finalize_done, 0));
+    // (an earlier frame of this slot failed half way: its queue counter was never reset -- before the pilot launch, which
+    // pulls from the same queue)
+    if (S.queue_dirty) HIP_TRY(c, hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), S.stream));
     // The tile queue is ordered by the per-tile cost this slot measured two frames ago, heaviest
     // first; before the slot's first frame of a scene a small pilot launch (no output) provides
     // the estimate when the frame is long enough to pay for it.  Without an estimate: index order.
@@ -1179,7 +1194,6 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
         }
     }
     const uint32_t ev = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
-    if (S.queue_dirty) HIP_TRY(c, hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), S.stream));   // an earlier frame of this slot failed half way
     S.queue_dirty = true;                        // until this frame's last finalize pass has been queued
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], S.stream));
     // A launch whose pixel chains are a handful of bounces (the reference's default: ONE frame of 1 sample per pixel) is bound
@@ -1268,7 +1282,7 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
     if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_read_pixel_costs: need %zu", n);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, sync_all(c));
-    const mrt_ctx::FrameSlot& S = c->slot[(c->frame_seq + mrt_ctx::kFrameSlots - 1u) % mrt_ctx::kFrameSlots];
+    const mrt_ctx::FrameSlot& S = c->slot[c->last_slot];
     std::vector<uint32_t> tmp(n * 4), layer(n * 4);
     HIP_TRY(c, hipMemcpyAsync(tmp.data(), (const char*)S.d_pix_acc + (size_t)S.cost_first_layer * n * 16, n * 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1452,6 +1466,12 @@ int mrt_debug_set_schedule(mrt_ctx* c, uint32_t pilot_spp, int waves_per_cu) {
     const uint32_t frames = c->frames_done;
     if (frames != 0) return fail(c, MRT_ERR_STATE, "mrt_debug_set_schedule: frames already rendered");
     return alloc_frame_buffers(c);
+}
+
+int mrt_debug_set_frames_in_flight(mrt_ctx* c, int slots) {
+    if (!c || slots < 0 || slots > (int)mrt_ctx::kMaxFrameSlots) return MRT_ERR_INVALID_ARG;
+    c->frame_slots_override = slots;
+    return MRT_OK;
 }
 
 // div_unscaled / sqrt_unscaled (kernels.hip) against hipcc's `/` and sqrtf(), on the device, over whole operand ranges

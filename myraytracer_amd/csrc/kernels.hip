@@ -36,6 +36,7 @@
 
 #include <hip/hip_runtime.h>
 #include "mrt_internal.h"
+#include "mrt_device.h"
 
 namespace mrt {
 namespace {
@@ -56,53 +57,6 @@ __device__ __forceinline__ float dot3(V3 a, V3 b) {
 }
 // WGSL normalize(e) = e / length(e)
 __device__ __forceinline__ V3 normalize3(V3 v) { return v / __builtin_sqrtf(dot3(v, v)); }
-// ---- IEEE division and square root without the operand scaling ------------------------------------------
-// `x / y` and sqrtf() compile to the correctly rounded expansions (v_div_scale x2, v_rcp, 7 fma-class operations,
-// v_div_fmas, v_div_fixup; a range test, v_sqrt, two residuals, two selects, a rescale and a class test).  The
-// functions below are those expansions WITHOUT the steps that only act on extreme operands, so wherever
-// v_div_scale_f32 would pass both operands through unscaled -- numerator and denominator finite and non-zero,
-// |n| >= 2^-102, the denominator and its reciprocal normal, -126 < exponent(n) - exponent(d) < 96 -- respectively
-// x >= 2^-96 finite, they execute the same operations on the same values and return the same bits as `/` and
-// sqrtf().  One refined reciprocal serves every numerator over the same denominator.  Each call site states why its
-// operands are in that range, or tests it and takes `/` and sqrtf() otherwise.
-struct Divisor { float d, r; };
-__device__ __forceinline__ Divisor divisor_of(float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    Divisor D; D.d = d; D.r = r;
-    return D;
-}
-__device__ __forceinline__ float div_unscaled(float n, const Divisor D) {
-    float q = n * D.r;
-    float e = __builtin_fmaf(-D.d, q, n);
-    q = __builtin_fmaf(e, D.r, q);
-    e = __builtin_fmaf(-D.d, q, n);
-    return __builtin_fmaf(e, D.r, q);
-}
-// (x = +0 -> +0: the neighbour below is a NaN pattern, whose comparison is false, and the residual of the neighbour
-// above is +0, not > 0)
-__device__ __forceinline__ float sqrt_unscaled(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);                 // within 1 ulp: the answer is s or one of its neighbours
-    const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
-    const float r_down = __builtin_fmaf(-down, s, x), r_up = __builtin_fmaf(-up, s, x);
-    s = (r_down <= 0.0f) ? down : s;
-    s = (r_up > 0.0f) ? up : s;
-    return s;
-}
-constexpr float kDivMinNum = 0x1p-90f, kDivMinDen = 0x1p-30f;       // the tested call sites' bounds (upper bounds: 2^30, from
-                                                                    // the ABI's |coordinate| <= 1e7, api.cpp)
-// The two call sites whose operands are TESTED (per wave: any lane failing sends its wave down the literal `/` and sqrtf()):
-// the hit normal (at - centre) / radius -- every component at least 2^-90 in magnitude (in particular not 0), |radius| >= 2^-30 --
-// and normalize(dir) = dir / sqrt(dot(dir, dir)) -- the same for the components, the squared length in [2^-60, 2^60).
-// mrt_debug_arith_pairs evaluates these very predicates for caller-supplied operands (tests/test_gpu_arith.py).
-__device__ __forceinline__ bool normal_unscaled_ok(float rel_min_abs, float radius) {
-    return rel_min_abs >= kDivMinNum && __builtin_fabsf(radius) >= kDivMinDen;
-}
-__device__ __forceinline__ bool normalize_unscaled_ok(float dd, float nd_min_abs) {
-    const bool dd_ok = (__float_as_uint(dd) - 0x21800000u) < (0x5D800000u - 0x21800000u);      // bits of 2^-60, 2^60
-    return dd_ok && nd_min_abs >= kDivMinNum;
-}
 // WGSL reflect(e1, e2) = e1 - 2*dot(e2, e1)*e2  (shader.wgsl:230)
 __device__ __forceinline__ V3 reflect3(V3 d, V3 n) {
     float k = 2.0f * dot3(n, d);
@@ -1279,15 +1233,8 @@ __global__ void __launch_bounds__(64) finalize_kernel(const KParams P) {
     if (lane == 0 && tile == 0) *P.tile_queue = 0u;
 }
 
-// Seed texture (Subject::new, lib.rs:389-415) generated on the device: SplitMix64 used as a
+// Seed texture (Subject::new, lib.rs:389-415) generated on the device: SplitMix64 (mrt_device.h) used as a
 // counter-based generator keyed by the GLOBAL pixel index, two outputs per pixel.
-__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
-    uint64_t z = seed + (k + 1u) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64_t seed, uint32_t W, uint32_t H,
                                                          uint32_t shard_rank, uint32_t shard_world,
                                                          uint32_t local_rows) {
@@ -1306,77 +1253,7 @@ __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64
     reinterpret_cast<uint4*>(seeds)[(size_t)lrow * W + px] = s;
 }
 
-// ---- mrt_debug_arith: the hand-rolled division / square root against hipcc's own, on the device ------------------------
-// div_unscaled / sqrt_unscaled replace the compiler's correctly rounded expansions at every root, normal and normalize of
-// the render kernel (shader.wgsl:286-299, :354, :381).  This kernel runs both forms side by side over whole operand ranges
-// and counts the operands whose results differ in any bit (two NaNs count as equal).
-//   mode 0: sqrt_unscaled(x) vs sqrtf(x) for EVERY f32 bit pattern in [r0, r1]
-//   mode 1: div_unscaled(n, divisor_of(d)) vs n / d for `count` pairs: |n| a bit pattern drawn uniformly from [r0, r1], |d|
-//           from [r2, r3], n of either sign; mode 2: d of either sign too
-// out[0] tested, out[1] mismatches, out[2] the smallest mismatching operand (mode 0: x; else bits(n) | bits(d) << 32)
-__device__ __forceinline__ bool same_bits_or_both_nan(float a, float b) {
-    return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
-}
-__device__ __forceinline__ uint32_t bits_in_range(uint32_t r, uint32_t lo, uint32_t hi) {
-    return lo + (uint32_t)(((unsigned long long)r * ((unsigned long long)(hi - lo) + 1ull)) >> 32);
-}
-__global__ void __launch_bounds__(256) arith_check_kernel(int mode, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3,
-                                                          unsigned long long count, unsigned long long seed,
-                                                          unsigned long long* out) {
-    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    unsigned long long bad = 0, first = ~0ull, tested = 0;
-    if (mode == 0) {
-        for (unsigned long long i = (unsigned long long)r0 + tid; i <= (unsigned long long)r1; i += stride) {
-            const float x = __uint_as_float((uint32_t)i);
-            tested++;
-            if (!same_bits_or_both_nan(sqrt_unscaled(x), __builtin_sqrtf(x))) { bad++; first = i < first ? i : first; }
-        }
-    } else {
-        for (unsigned long long i = tid; i < count; i += stride) {
-            const unsigned long long z = splitmix64_at(seed, i);
-            uint32_t nb = bits_in_range((uint32_t)z, r0, r1), db = bits_in_range((uint32_t)(z >> 32), r2, r3);
-            const unsigned long long z2 = splitmix64_at(seed ^ 0x5851F42D4C957F2Dull, i);
-            nb |= (uint32_t)(z2 & 1u) << 31;
-            if (mode == 2) db |= (uint32_t)(z2 & 2u) << 30;
-            const float n = __uint_as_float(nb), d = __uint_as_float(db);
-            tested++;
-            if (!same_bits_or_both_nan(div_unscaled(n, divisor_of(d)), n / d)) {
-                const unsigned long long key = (unsigned long long)nb | ((unsigned long long)db << 32);
-                bad++; first = key < first ? key : first;
-            }
-        }
-    }
-    atomicAdd(out + 0, tested);
-    if (bad) { atomicAdd(out + 1, bad); atomicMin(out + 2, first); }
-}
-// caller-supplied operands: out[6 i ..] = bits(x / y), bits(div_unscaled(x, y)), bits(sqrtf(x)), bits(sqrt_unscaled(x)),
-// normal_unscaled_ok(|x|, y) (x a component of at - centre, y the radius), normalize_unscaled_ok(x, |y|) (x the squared
-// length, y a component)
-__global__ void __launch_bounds__(256) arith_pairs_kernel(const float* x, const float* y, uint32_t n, uint32_t* out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float a = x[i], b = y[i];
-    out[6u * i + 0u] = __float_as_uint(a / b);
-    out[6u * i + 1u] = __float_as_uint(div_unscaled(a, divisor_of(b)));
-    out[6u * i + 2u] = __float_as_uint(__builtin_sqrtf(a));
-    out[6u * i + 3u] = __float_as_uint(sqrt_unscaled(a));
-    out[6u * i + 4u] = normal_unscaled_ok(__builtin_fabsf(a), b) ? 1u : 0u;
-    out[6u * i + 5u] = normalize_unscaled_ok(a, __builtin_fabsf(b)) ? 1u : 0u;
-}
-
 }  // namespace
-
-int launch_arith_check(int mode, const uint32_t r[4], unsigned long long count, unsigned long long seed, unsigned long long* d_out,
-                       void* stream) {
-    hipLaunchKernelGGL(arith_check_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, mode, r[0], r[1], r[2], r[3], count, seed, d_out);
-    return (int)hipGetLastError();
-}
-int launch_arith_pairs(const float* d_x, const float* d_y, uint32_t n, uint32_t* d_out, void* stream) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(arith_pairs_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d_x, d_y, n, d_out);
-    return (int)hipGetLastError();
-}
 
 // SMALL scenes (every node id < 1024): member records live in LDS and work items are u16
 static bool scene_is_small(const KParams& p) { return p.n_members <= 1024u; }

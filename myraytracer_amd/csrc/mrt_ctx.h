@@ -56,11 +56,19 @@ struct mrt_ctx {
     unsigned long long* d_counters = nullptr;
     bool count_draws = true;               // mrt_set_draw_counting
     uint32_t last_launch[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};   // mrt_debug_last_launch: the last render / pilot instantiation
-    // Up to kFrameSlots frames may be in flight: frame n's render kernel (sort, pilot) runs on side
-    // stream n % kFrameSlots and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
+    // Up to frame_slots frames may be in flight: frame n's render kernel (sort, pilot) runs on side
+    // stream n % frame_slots and only its finalize pass -- the one step that needs frame n-1's framebuffer -- runs
     // on the caller's stream.  The next frame's heavy tiles thus start while this frame's last
     // pixels drain (a pixel is one sequential chain, so every frame ends on a thinning chip).
-    static constexpr uint32_t kFrameSlots = 2;      // re-measured in round 2 (LDS-free sort): C3 9,799 / 9,709 / 9,380 Msamples/s with 2 / 3 / 4
+    // How many: 2 for launches that fill the chip (re-measured in round 2, LDS-free sort: C3 9,799 / 9,709 / 9,380 Msamples/s
+    // with 2 / 3 / 4).  A PIXEL-STARVED shard (fewer than two pixels per resident lane, long sample chains: an 8-GPU share of
+    // C5) is different: its launch is as long as its heaviest pixel's chain while most of its waves end much earlier, and a
+    // wave instruction costs the same with 40 % of its lanes active as with all -- so it runs more frames at once, each on
+    // fewer, better packed waves (redraw_frames; round 4).  frame_slots is the count in use, slot[] the capacity.
+    static constexpr uint32_t kMaxFrameSlots = 8;
+    uint32_t frame_slots = 2;
+    uint32_t last_slot = 0;                         // the slot of the most recent redraw
+    int frame_slots_override = 0;                   // mrt_debug_set_frames_in_flight: 0 = automatic
     struct FrameSlot {
         hipStream_t stream = nullptr;
         hipEvent_t render_done = nullptr, finalize_done = nullptr;
@@ -74,7 +82,7 @@ struct mrt_ctx {
         // The tile queue's counter is left at zero by every finalize pass of the slot.  If anything between a render launch
         // and its last finalize launch fails, it is not: the next launch on this slot resets it itself.
         bool queue_dirty = false;
-    } slot[kFrameSlots];
+    } slot[kMaxFrameSlots];
     hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
     bool inputs_dirty = true;
     uint64_t frame_seq = 0;

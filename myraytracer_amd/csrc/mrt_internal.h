@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 #include "../../include/myraytracer_amd.h"
+#include "../../include/myraytracer_amd_debug.h"
 
 namespace mrt {
 

@@ -83,12 +83,40 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def lib():
+_readings = {}
+
+
+class reading:
+    """with pyoracle.reading("nofma"): ... -- every call inside runs the oracle built with the OTHER legal reading of the
+    shader's arithmetic (no fused multiply-add anywhere; oracle/Makefile, rt_oracle.c ORC_READING_NOFMA).  Only for
+    scripts/reading_spread.py / tests/test_reading_spread.py: it is never what the GPU path is compared with."""
+
+    def __init__(self, name):
+        assert name == "nofma"
+        self.path = os.path.join(_HERE, "librt_oracle_nofma.so")
+
+    def __enter__(self):
+        global _lib
+        self.saved = lib()
+        if self.path not in _readings:
+            if not os.path.exists(self.path):
+                build()
+            _lib = None
+            _readings[self.path] = lib(self.path)
+        _lib = _readings[self.path]
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+
+
+def lib(path=None):
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        if not os.path.exists(path or _LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path or _LIB_PATH)
         L.orc_xoshiro128plus_next.restype = C.c_uint32
         L.orc_xoshiro128plus_next.argtypes = [C.POINTER(C.c_uint32)]
         L.orc_u32_to_f32.restype = C.c_float

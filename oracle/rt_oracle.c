@@ -24,8 +24,18 @@ static inline v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
 static inline v3 v3_divs(v3 a, float s) { return v3_make(a.x / s, a.y / s, a.z / s); }
 
 /* WGSL dot(); MRT-F32: fma chain x, then y, then z */
+/* Which legal reading of WGSL's arithmetic the oracle takes.  Default = "MRT-F32" (DESIGN.md 3): dot() and the discriminant
+ * as fma chains.  -DORC_READING_NOFMA builds the OTHER common lowering -- dot(a, b) = a.x*b.x + a.y*b.y + a.z*b.z with every
+ * product and sum rounded separately, no fused operation anywhere (shader.wgsl:277-280 leave this to naga's backend) -- as
+ * librt_oracle_nofma.so: never a parity target, only the yardstick of scripts/reading_spread.py, which measures how far two
+ * legal readings of the reference sit from each other. */
+#ifdef ORC_READING_NOFMA
+#define ORC_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define ORC_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#endif
 static inline float dot3(v3 a, v3 b) {
-    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+    return ORC_FMA(a.z, b.z, ORC_FMA(a.y, b.y, a.x * b.x));
 }
 /* WGSL normalize(e) = e / length(e) */
 static inline v3 normalize3(v3 v) { return v3_divs(v, sqrtf(dot3(v, v))); }
@@ -154,15 +164,29 @@ static inline float sphere_load_radius(const scene_t* s, int32_t idx) {
 
 typedef struct { v3 at; float t; v3 normal; int front_face; int32_t ty, idx; } hit_t;
 
+/* shader.wgsl:280: c = dot(oc, oc) - radius * radius.  MRT-F32 folds -r^2 into the head of the fma chain; the
+ * no-fma reading evaluates the text as written */
+static inline float sphere_c(v3 oc, float radius) {
+#ifdef ORC_READING_NOFMA
+    return dot3(oc, oc) - radius * radius;
+#else
+    return __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -(radius * radius))));
+#endif
+}
+
 /* shader.wgsl:274-282: a, b and the discriminant d of sphere_hit (what `if d < 0 { return false }` tests) */
 static inline float sphere_discriminant(v3 center, float radius, v3 orig, v3 dir, float* a_out, float* b_out) {
     v3 oc = v3_sub(orig, center);
     float a = dot3(dir, dir);
     float b = dot3(oc, dir);
     /* c = dot(oc,oc) - radius*radius, MRT-F32 form (see header) */
-    float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -(radius * radius))));
+    float c = sphere_c(oc, radius);
     *a_out = a; *b_out = b;
+#ifdef ORC_READING_NOFMA
+    return b * b - a * c;                               /* :282 as written */
+#else
     return __builtin_fmaf(b, b, -(a * c));
+#endif
 }
 
 /* shader.wgsl:270-312 sphere_hit */
@@ -349,7 +373,7 @@ static inline void camera_ray(const orc_camera_raw* cam, float vx, float vy, rng
         do {
             float qx = rand_f32(rng); float qy = rand_f32(rng);
             px = 2.0f * qx - 1.0f; py = 2.0f * qy - 1.0f;
-        } while (__builtin_fmaf(py, py, px * px) > 1.0f);
+        } while (ORC_FMA(py, py, px * px) > 1.0f);
         v3 off = v3_make(px * cam->ru[0] + py * cam->rv[0],
                          px * cam->ru[1] + py * cam->rv[1],
                          px * cam->ru[2] + py * cam->rv[2]);
@@ -525,7 +549,7 @@ void orc_world_hit_batch(const orc_world* w, const float* vec4, const float* f32
                 /* bit 0: discriminant not < 0.  bit 1: additionally the sphere is not entirely behind the origin, i.e. NOT
                  * (b >= +0 and c >= +0) -- with both non-negative, sqrt(d) <= b and neither root of :290-292 reaches t_min. */
                 const v3 oc = v3_sub(o, ctr);
-                const float c = __builtin_fmaf(oc.z, oc.z, __builtin_fmaf(oc.y, oc.y, __builtin_fmaf(oc.x, oc.x, -(rad * rad))));
+                const float c = sphere_c(oc, rad);
                 uint32_t bb, cb; memcpy(&bb, &b, 4); memcpy(&cb, &c, 4);
                 const int ge0 = !(disc < 0.0f), ahead = ((bb | cb) >> 31) != 0u;
                 disc_ge0[r * ns + i] = (uint8_t)(ge0 | ((ge0 && ahead) << 1));

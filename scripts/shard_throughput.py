@@ -18,12 +18,14 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 
         assert _lib.load().mrt_debug_set_hierarchy(st._ctx, h_[0], h_[1]) == 0
     if os.environ.get("MRT_WAVES_PER_CU"):   # persistent waves per CU (0 = what the kernel's registers / LDS admit)
         assert _lib.load().mrt_debug_set_schedule(st._ctx, 1, int(os.environ["MRT_WAVES_PER_CU"])) == 0
+    if os.environ.get("MRT_SLOTS"):          # frames in flight
+        assert _lib.load().mrt_debug_set_frames_in_flight(st._ctx, int(os.environ["MRT_SLOTS"])) == 0
     if os.environ.get("MRT_NOBATCH"):     # mrt_render without sharing launches among frames
         assert _lib.load().mrt_debug_set_frame_batching(st._ctx, 0) == 0
     if os.environ.get("MRT_CLUSTER"):
         _lib.load().mrt_debug_set_cluster_factor(st._ctx, float(os.environ["MRT_CLUSTER"]))
     st.set_world(sp); st.set_camera(cam); st.set_rng_mode(mode)
-    st.render(2); st.sync()
+    st.render(max(2, int(os.environ.get('MRT_SLOTS', '2')))); st.sync()
     c0 = st.read_counters()
     t0 = time.perf_counter(); st.render(K); st.sync(); dt = time.perf_counter() - t0
     c1 = st.read_counters()

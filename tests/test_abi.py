@@ -1,4 +1,5 @@
-"""The C-ABI library loads without a GPU and exports exactly what include/myraytracer_amd.h declares."""
+"""The C-ABI library loads without a GPU and exports exactly what include/myraytracer_amd.h (the drop-in boundary) and
+include/myraytracer_amd_debug.h (diagnostics) declare."""
 import ctypes as C
 import os
 import re
@@ -7,12 +8,25 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "myraytracer_amd.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "myraytracer_amd_debug.h")
 
 
-def header_functions():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mrt_[a-z0-9_]+)\s*\(", text)))
+def header_functions(path=None):
+    names = set()
+    for h in ([path] if path else [HEADER, DEBUG_HEADER]):
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(mrt_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_the_boundary_header_holds_no_diagnostics():
+    """include/myraytracer_amd.h is what INTEGRATION.md cites as the drop-in boundary: every mrt_debug_* entry point lives in
+    the debug header, and only there."""
+    product, debug = header_functions(HEADER), header_functions(DEBUG_HEADER)
+    assert not [n for n in product if n.startswith("mrt_debug_")]
+    assert debug and all(n.startswith("mrt_debug_") for n in debug)
+    assert "myraytracer_amd_debug.h" not in open(os.path.join(ROOT, "INTEGRATION.md")).read().split("## 1.")[1].split("## 2.")[0]
 
 
 def test_every_declared_symbol_is_exported(mrt):
@@ -28,10 +42,22 @@ def test_every_declared_symbol_is_exported(mrt):
 def test_abi_version_and_status_strings(mrt):
     from myraytracer_amd import _lib
     L = _lib.load()
-    assert L.mrt_abi_version() == 2
+    assert L.mrt_abi_version() == 3
     assert L.mrt_status_string(0) == b"ok"
     assert L.mrt_status_string(2) == b"no usable HIP device"
     assert L.mrt_last_error(None) is not None
+
+
+def test_build_id_names_the_sources_on_disk(mrt):
+    """mrt_build_id() (baked in by the Makefile) equals scripts/source_hash.py over the sources here: the library under test
+    was built from this tree (bench.py refuses a headline otherwise)."""
+    import sys
+    from myraytracer_amd import _lib
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from source_hash import source_sha16
+    if os.environ.get("MRT_LIB_OVERRIDE"):
+        pytest.skip("a substituted library")
+    assert _lib.load().mrt_build_id().decode() == source_sha16()
 
 
 def test_struct_sizes_match_reference_layouts(mrt):
