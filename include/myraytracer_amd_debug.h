@@ -86,12 +86,13 @@ int mrt_debug_arith(mrt_ctx* ctx, int mode, const uint32_t bits_range[4], uint64
 int mrt_debug_arith_pairs(mrt_ctx* ctx, const float* x, const float* y, size_t n, uint32_t* out);
 /* Diagnostic: which instantiation of the render kernel the most recent redraw launched (out[0]) and, if it was preceded by
  * a cost-estimating pilot launch not yet reported, which one that was (out[1], else 0xFFFFFFFF): bit 0 = with the RNG draw
- * counter, 1 = pilot, 2 = counter-RNG mode, 3 = small-scene layout, 4 = matrix-core sweep
+ * counter, 1 = pilot, 2 = counter-RNG mode, 3 = small-scene layout, 4 = matrix-core sweep, 5 = large-scene layout with the
+ * quadratic form of the box test's slack (else the linear form)
  * (tests/test_gpu_parity.py::test_every_render_kernel_instantiation_against_the_oracle). */
 int mrt_debug_last_launch(mrt_ctx* ctx, uint32_t out[2]);
-/* Diagnostic A/B switch (large scenes, > 1,024 member slots): 0 makes the walk test only the bounding spheres, as small
- * scenes do; 1 (default) also the axis-aligned boxes of the hierarchy's nodes where that pays (beyond 4,096 member slots);
- * 2 wherever the layout allows (every large scene).  Either way the image is the same. */
+/* Diagnostic A/B switch (large scenes, > 1,024 member slots, whose walk tests the axis-aligned box of every node): 0 opens
+ * every box wide, so that the box tests never reject and the walk reaches every member below the swept candidates; 1 (default)
+ * and 2: the real boxes.  Either way the image is the same.  Takes effect at the next redraw. */
 int mrt_debug_set_boxes(mrt_ctx* ctx, int mode);
 /* Which variant the next redraw will run with the current scene, camera and mode: 1 or 2 (0 before a scene is set). */
 int mrt_debug_sweep_variant(mrt_ctx* ctx);
@@ -104,6 +105,11 @@ int mrt_debug_set_tile_sort(mrt_ctx* ctx, int enabled);
 /* Diagnostic / tuning: pilot samples per pixel, waves per CU (0 = automatic).  Before the first
  * redraw only. */
 int mrt_debug_set_schedule(mrt_ctx* ctx, uint32_t pilot_spp, int waves_per_cu);
+/* Host-side diagnostic, no GPU needed: the LDS footprint of the render kernel for a scene with this hierarchy (the sizes
+ * mrt_debug_build_hierarchy reports): out[3] = {bytes per workgroup of 4 waves, workgroups resident per CU (160 KB of LDS;
+ * large scenes: at most 4, the occupancy their kernels are built for), entries of a wave's top queue (small scenes) / work
+ * stack (large scenes)}.  tests/test_hierarchy_host.py pins the residency of C3's and C5's layouts with it. */
+int mrt_debug_lds_layout(uint32_t n_members, uint32_t n_nodes, uint32_t levels, uint32_t n_top_padded, uint32_t out[3]);
 /* Diagnostic / tuning: how many frames may be in flight (each on a side stream of its own; 1..8), 0 = automatic: 2, more for
  * pixel-starved shards.  A change waits for the frames under way.  The images are the same. */
 int mrt_debug_set_frames_in_flight(mrt_ctx* ctx, int slots);

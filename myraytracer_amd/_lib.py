@@ -9,6 +9,11 @@ import importlib.util
 import os
 import sys
 
+# Up to 8 frames of a pixel-starved shard run at a time, each on a HIP stream of its own (api.cpp, redraw_frames); they only
+# run side by side on hardware queues of their own, and HIP's default is 4 per process.  Read by the runtime when it
+# initialises -- set here, at import, before anything (torch included) has made a HIP call.  Never overrides the caller's value.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRT_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libmyraytracer_amd.so")
 
@@ -25,7 +30,7 @@ EXPORTS = [
     "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_build_id", "mrt_scene_default", "mrt_scene_cover",
     "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
     "mrt_srgb8", "mrt_write_png", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
-    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit", "mrt_debug_set_frame_batching", "mrt_debug_set_gather_per_band", "mrt_debug_arith", "mrt_debug_arith_pairs", "mrt_debug_set_boxes", "mrt_debug_build_boxes", "mrt_set_draw_counting", "mrt_debug_last_launch", "mrt_debug_set_frames_in_flight",
+    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit", "mrt_debug_set_frame_batching", "mrt_debug_set_gather_per_band", "mrt_debug_arith", "mrt_debug_arith_pairs", "mrt_debug_set_boxes", "mrt_debug_build_boxes", "mrt_set_draw_counting", "mrt_debug_last_launch", "mrt_debug_set_frames_in_flight", "mrt_debug_lds_layout",
 ]
 
 
@@ -250,6 +255,7 @@ def load():
         "mrt_set_draw_counting": (i32, [vp, i32]),
         "mrt_debug_last_launch": (i32, [vp, P(u32)]),
         "mrt_debug_set_frames_in_flight": (i32, [vp, i32]),
+        "mrt_debug_lds_layout": (i32, [u32, u32, u32, u32, P(u32)]),
     }
     assert sorted(sig) == sorted(EXPORTS)
     for name, (res, args) in sig.items():

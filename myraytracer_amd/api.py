@@ -402,13 +402,17 @@ class State:
         self._check(self._L.mrt_debug_last_launch(self._ctx, out), "mrt_debug_last_launch")
         return int(out[0]), (None if out[1] == 0xFFFFFFFF else int(out[1]))
 
+    def debug_set_frames_in_flight(self, slots: int):
+        """How many frames may be in flight, each on a side stream of its own (1..8; 0 = automatic)."""
+        self._check(self._L.mrt_debug_set_frames_in_flight(self._ctx, slots), "mrt_debug_set_frames_in_flight")
+
     def debug_set_schedule(self, pilot_spp: int, waves_per_cu: int):
         """Before the first redraw: samples per pixel of the pilot launch, persistent waves per CU (0 = automatic)."""
         self._check(self._L.mrt_debug_set_schedule(self._ctx, pilot_spp, waves_per_cu), "mrt_debug_set_schedule")
 
     def debug_set_boxes(self, mode):
-        """A/B switch (large scenes): 0 / False = the walk tests bounding spheres only, 1 = automatic (boxes beyond 4,096
-        member slots), 2 / True = boxes for every large scene; the image is the same."""
+        """A/B switch (large scenes, whose walk tests every node's axis-aligned box): 0 / False = the boxes are opened wide and
+        never reject, 1 / 2 / True = the real boxes (default); the image is the same."""
         self._check(self._L.mrt_debug_set_boxes(self._ctx, 2 if mode is True else int(mode)), "mrt_debug_set_boxes")
 
     def debug_arith(self, mode: int, bits_range: Sequence[int], count: int = 0, seed: int = 1):

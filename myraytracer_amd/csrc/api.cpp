@@ -16,6 +16,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -79,13 +80,14 @@ void free_world(mrt_ctx* c) {
     if (c->d_clusters) (void)hipFree(c->d_clusters);
     if (c->d_nodes) (void)hipFree(c->d_nodes);
     if (c->d_boxes) (void)hipFree(c->d_boxes);
+    if (c->d_boxes_open) (void)hipFree(c->d_boxes_open);
     if (c->d_shade) (void)hipFree(c->d_shade);
     if (c->d_top_mfma) (void)hipFree(c->d_top_mfma);
     if (c->d_member_index) (void)hipFree(c->d_member_index);
     if (c->d_vec4) (void)hipFree(c->d_vec4);
     if (c->d_f32) (void)hipFree(c->d_f32);
     if (c->d_i32) (void)hipFree(c->d_i32);
-    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_boxes = nullptr; c->d_shade = nullptr; c->d_top_mfma = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
+    c->d_spheres = nullptr; c->d_clusters = nullptr; c->d_nodes = nullptr; c->d_boxes = nullptr; c->d_boxes_open = nullptr; c->d_shade = nullptr; c->d_top_mfma = nullptr; c->d_member_index = nullptr; c->d_vec4 = nullptr; c->d_f32 = nullptr; c->d_i32 = nullptr;
     c->have_world = false;
 }
 
@@ -428,6 +430,30 @@ void build_boxes(const float* centers4, const float* radii, const std::vector<mr
     }
 }
 
+// The boxes in the order the kernel walks them (KParams::boxes): depth t of the hierarchy (0 = the swept top = level
+// `levels`, levels - 1 = the clusters = level 1) at o_t = n_top (4^t - 1) / 3, n_top = the padded top: the children of node g
+// are 4 g + n_top .. + 3 whatever its depth, so a work item needs no level.  Slots without a node hold never-hit boxes.
+// `open`: every real box opened wide (extents 3e37: the test never rejects) -- the A/B form of mrt_debug_set_boxes(0).
+void boxes_top_down(const Hierarchy& H, bool open, std::vector<mrt::BoxRec>& out, uint32_t* cluster_first, uint32_t* cluster_parent_first) {
+    const mrt::BoxRec never_box{0.0f, 0.0f, 0.0f, -3.0e38f, -3.0e38f, -3.0e38f, 0.0f, 0.0f};
+    const size_t n_top = H.top.size();
+    size_t o[mrt::kMaxLevels + 1];
+    o[0] = 0;
+    for (uint32_t t = 0; t < H.levels; t++) o[t + 1] = o[t] + (n_top << (2 * t));
+    out.assign(o[H.levels], never_box);
+    for (uint32_t t = 0; t < H.levels; t++) {
+        const uint32_t k = H.levels - t;                 // the level at this depth
+        const size_t first = H.box_base[k], last = k < H.levels ? H.box_base[k + 1] : H.boxes.size();
+        for (size_t j = 0; j < last - first && j < (n_top << (2 * t)); j++) {
+            mrt::BoxRec b = H.boxes[first + j];
+            if (open && b.ex >= 0.0f) b.ex = b.ey = b.ez = 3.0e37f;
+            out[o[t] + j] = b;
+        }
+    }
+    *cluster_first = (uint32_t)o[H.levels - 1];
+    *cluster_parent_first = H.levels >= 2 ? (uint32_t)o[H.levels - 2] : 0u;
+}
+
 constexpr uint32_t kBoxMinMembers = 4096;     // member slots from which the walk tests boxes by default (fill_scene_params)
 void build_hierarchy(const float* centers4, const float* radii, uint32_t n, float factor, uint32_t max_levels,
                      uint32_t top_target, Hierarchy& H) {
@@ -584,7 +610,16 @@ bool use_matrix_core_sweep(const mrt_ctx* c) {
     return kMfmaSlack * o2 <= 0.1 * c->mfma_r2_ref;
 }
 
-// wait for everything this context has in flight (caller's stream and both side streams)
+// the side stream of a frame slot and its two events
+hipError_t create_slot_streams(mrt_ctx::FrameSlot& S) {
+    hipError_t e = hipSuccess;
+    if (!S.stream) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+    if (e == hipSuccess && !S.render_done) e = hipEventCreateWithFlags(&S.render_done, hipEventDisableTiming);
+    if (e == hipSuccess && !S.finalize_done) e = hipEventCreateWithFlags(&S.finalize_done, hipEventDisableTiming);
+    return e;
+}
+
+// wait for everything this context has in flight (caller's stream and the side streams)
 hipError_t sync_all(mrt_ctx* c) {
     hipError_t e = hipSuccess, r;
     for (auto& S : c->slot)
@@ -746,6 +781,13 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
     mrt_args_resolve_size(&a);
     if (a.width > (1u << 20) || a.height > (1u << 20))
         return fail(nullptr, MRT_ERR_INVALID_ARG, "mrt_create: image %ux%u too large", a.width, a.height);
+    // The frames in flight of a pixel-starved shard (redraw_frames: up to 8, each on a side stream of its own) must really run
+    // side by side, i.e. on hardware queues of their own.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default
+    // 4) hardware queues and kernels of streams that share one serialise (measured, round 4: 8 frames in flight ran 2.7 at a
+    // time; with 16 queues all 8: C5's 1/8 share 1,050 -> 2,370 Msamples/s).  The runtime reads the variable when it
+    // initialises, so this only helps if no HIP call has been made in the process yet; a host that initialises HIP first sets
+    // it itself (bench.py and the Python package do).  Never overrides the caller's value.
+    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, MRT_ERR_NO_DEVICE, "mrt_create: no HIP device (this backend has no CPU fallback)");
@@ -766,10 +808,9 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) { c->err = "hipSetDevice failed"; return bail(MRT_ERR_HIP); }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate failed"; return bail(MRT_ERR_HIP); }
     c->stream = c->own_stream;
-    for (auto& S : c->slot)
-        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&S.render_done, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&S.finalize_done, hipEventDisableTiming) != hipSuccess) { c->err = "side stream creation failed"; return bail(MRT_ERR_HIP); }
+    // (slots 0 and 1 now; the further ones -- pixel-starved shards only -- when redraw_frames first needs them)
+    for (uint32_t i = 0; i < 2; i++)
+        if (create_slot_streams(c->slot[i]) != hipSuccess) { c->err = "side stream creation failed"; return bail(MRT_ERR_HIP); }
     if (hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
     for (uint32_t i = 0; i < mrt_ctx::kEventRing; i++)
         if (hipEventCreate(&c->ev_start[i]) != hipSuccess || hipEventCreate(&c->ev_stop[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
@@ -889,8 +930,13 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
     HIP_TRY(c, upload((void**)&c->d_spheres, recs.data(), recs.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_clusters, hier.top.data(), hier.top.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_nodes, hier.nodes.data(), hier.nodes.size() * sizeof(mrt::SphereRec)));
-    HIP_TRY(c, upload((void**)&c->d_boxes, hier.boxes.data(), hier.boxes.size() * sizeof(mrt::BoxRec)));
-    for (uint32_t k = 0; k <= mrt::kMaxLevels; k++) c->box_base[k] = hier.box_base[k];
+    if (hier.n_members > 1024u) {           // large scenes (the kernel's !SMALL layouts) walk the boxes
+        std::vector<mrt::BoxRec> dev;
+        boxes_top_down(hier, false, dev, &c->box_cluster_first, &c->box_cluster_parent_first);
+        HIP_TRY(c, upload((void**)&c->d_boxes, dev.data(), dev.size() * sizeof(mrt::BoxRec)));
+        boxes_top_down(hier, true, dev, &c->box_cluster_first, &c->box_cluster_parent_first);
+        HIP_TRY(c, upload((void**)&c->d_boxes_open, dev.data(), dev.size() * sizeof(mrt::BoxRec)));
+    }
     c->box_quad = hier.box_quad;
     {
         std::vector<uint16_t> top_mfma;
@@ -1079,15 +1125,12 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
         mfma_scales(std::max(c->mfma_reach, std::sqrt(cam_d2) + lens), p.mfma_scale, &p.mfma_neg_k2_pair);
     }
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
-    p.gen_cap = c->levels == 1 ? 576u : 320u;      // the top queue holds a ray's candidates among ALL top records
+    // small scenes: the top queue holds a ray's candidates among ALL top records; large scenes: the wave's one work stack
+    p.gen_cap = c->n_members <= 1024u ? 576u : mrt::large_scene_stack_cap(p.mask_chunks);
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) p.level_base[k] = c->level_base[k];
-    p.boxes = c->d_boxes;
-    for (uint32_t k = 0; k <= mrt::kMaxLevels; k++) p.box_base[k] = c->box_base[k];
-    p.box_top = c->box_base[c->levels];
-    // large scenes only (kernels.hip: !SMALL), and by default only beyond kBoxMinMembers member slots: below, a filter round
-    // costs what it saves (1,297 / 2,501 spheres: 17.0 / 23.0 ms per 64-spp frame without boxes, 17.6 / 23.5 with; 4,901 /
-    // 10,001: 38.6 / 57.2 without, 33.3 / 47.3 with)
-    p.use_boxes = (c->n_members > 1024u && (c->boxes_mode == 2 || (c->boxes_mode == 1 && c->n_members > kBoxMinMembers))) ? 1u : 0u;
+    // large scenes only (kernels.hip: !SMALL): every node's box, in the kernel's top-down numbering
+    p.boxes = c->boxes_mode == 0 ? c->d_boxes_open : c->d_boxes;
+    p.box_cluster_first = c->box_cluster_first; p.box_cluster_parent_first = c->box_cluster_parent_first;
     p.box_quad = c->box_quad ? 1u : 0u;
     p.n_direct = c->n_direct; p.direct_first = c->direct_first;
     for (uint32_t k = 0; k < mrt::kMaxDirect; k++) { p.direct[k] = c->direct[k]; p.direct_index[k] = c->direct_index[k]; }
@@ -1118,11 +1161,30 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
     p.pilot_spp = c->pilot_spp;
     // how many frames may be in flight from here on (mrt_ctx::kMaxFrameSlots); a change waits for the frames under way
+    bool starved = false;
     {
-        const uint32_t want = c->frame_slots_override > 0 ? (uint32_t)c->frame_slots_override : 2u;
+        // A pixel-starved launch of long chains (fewer than two pixels per lane the chip holds, one sequential chain of >= 64
+        // samples each: an 8-GPU share of C5) lasts as long as its heaviest pixel while most of its waves are done far earlier,
+        // and a wave's iteration takes the same time at 1 to 4 waves per SIMD.  So such frames run EIGHT at a time on an eighth
+        // of the waves each: the lanes stay packed (8 pixels per lane in sequence) and the chip full.  Measured on C5's 1/8
+        // share, one mrt_redraw per frame: 885 Msamples/s at 0.41 lane utilisation (2 frames in flight on all waves) ->
+        // 2,367 at 0.92 (DESIGN_HISTORY.md, round 4).
+        starved = !counter && batch == 1 && c->locals.samples_per_frame >= 64u && c->waves_per_cu_override == 0 &&
+                  (uint64_t)c->n_tiles < 2ull * c->n_waves && c->n_tiles > c->n_waves / mrt_ctx::kMaxFrameSlots;
+        const uint32_t want = c->frame_slots_override > 0 ? (uint32_t)c->frame_slots_override : starved ? mrt_ctx::kMaxFrameSlots : 2u;
         if (want != c->frame_slots) {
             HIP_TRY(c, sync_all(c));
             c->frame_slots = want;
+            // the further slots' colour sums now, in one go: allocated on first use each would wait for the frames in flight
+            for (uint32_t i = 0; i < want; i++) {
+                mrt_ctx::FrameSlot& T = c->slot[i];
+                HIP_TRY(c, create_slot_streams(T));
+                if (T.pix_acc_layers != 0) continue;
+                const size_t nt = local_texels(c) ? local_texels(c) : 1;
+                HIP_TRY(c, hipMalloc(&T.d_pix_acc, nt * 16));
+                HIP_TRY(c, hipMemsetAsync(T.d_pix_acc, 0, nt * 16, c->stream));
+                T.pix_acc_layers = 1;
+            }
         }
     }
     c->last_slot = (uint32_t)(c->frame_seq % c->frame_slots);
@@ -1181,9 +1243,15 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     // With no more tiles than persistent waves every tile starts at once and the order cannot matter: no pilot, no sort.
     // ... nor when a pixel's chain is a handful of bounces (fewer than 4 samples per pixel and launch): three launches saved.
     const uint32_t chain_spp = c->locals.samples_per_frame * p.lane_frames;
-    if (c->lpt_enabled && c->n_tiles > c->n_waves && chain_spp >= 4u) {
+    // A launch whose pixel chains are a handful of bounces (the reference's default: ONE frame of 1 sample per pixel) is bound
+    // by its longest path -- up to ray_depth wave-iterations in sequence -- not by throughput: with fewer resident waves every
+    // iteration is shorter (1080p, 1 spp: 20 waves per CU 0.74 ms, 8 waves 0.42 ms; DESIGN_HISTORY.md round 3).
+    uint32_t launch_waves = c->n_waves;
+    if (chain_spp < 4u && c->waves_per_cu_override == 0) launch_waves = std::min(launch_waves, c->cus * 8u);
+    if (starved) launch_waves = std::max(c->n_waves / c->frame_slots, 1u);         // (above: frames in flight)
+    if (c->lpt_enabled && c->n_tiles > launch_waves && chain_spp >= 4u) {
         if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
-            int pe = mrt::launch_render(p, true, c->n_waves, S.stream, &c->last_launch[1]);
+            int pe = mrt::launch_render(p, true, launch_waves, S.stream, &c->last_launch[1]);
             if (pe) return fail(c, MRT_ERR_HIP, "pilot launch failed: %s", hipGetErrorString((hipError_t)pe));
             S.cost_valid = true;
         }
@@ -1196,11 +1264,6 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     const uint32_t ev = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
     S.queue_dirty = true;                        // until this frame's last finalize pass has been queued
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], S.stream));
-    // A launch whose pixel chains are a handful of bounces (the reference's default: ONE frame of 1 sample per pixel) is bound
-    // by its longest path -- up to ray_depth wave-iterations in sequence -- not by throughput: with fewer resident waves every
-    // iteration is shorter (1080p, 1 spp: 20 waves per CU 0.74 ms, 8 waves 0.42 ms; DESIGN_HISTORY.md round 3).
-    uint32_t launch_waves = c->n_waves;
-    if (chain_spp < 4u && c->waves_per_cu_override == 0) launch_waves = std::min(launch_waves, c->cus * 8u);
     int e = mrt::launch_render(p, false, launch_waves, S.stream, &c->last_launch[0]);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], S.stream));
@@ -1466,6 +1529,19 @@ int mrt_debug_set_schedule(mrt_ctx* c, uint32_t pilot_spp, int waves_per_cu) {
     const uint32_t frames = c->frames_done;
     if (frames != 0) return fail(c, MRT_ERR_STATE, "mrt_debug_set_schedule: frames already rendered");
     return alloc_frame_buffers(c);
+}
+
+int mrt_debug_lds_layout(uint32_t n_members, uint32_t n_nodes, uint32_t levels, uint32_t n_top_padded, uint32_t out[3]) {
+    if (!out || levels < 1 || levels > mrt::kMaxLevels) return MRT_ERR_INVALID_ARG;
+    mrt::KParams p;
+    std::memset(&p, 0, sizeof p);
+    p.n_members = n_members; p.n_nodes = n_nodes; p.levels = levels; p.n_padded = n_top_padded;
+    { const uint32_t ch = (n_top_padded + mrt::kChunk - 1) / mrt::kChunk; p.mask_chunks = ch < 16u ? ch : 16u; }
+    p.gen_cap = n_members <= 1024u ? 576u : mrt::large_scene_stack_cap(p.mask_chunks);
+    uint32_t lay[2];
+    mrt::render_lds_layout(p, lay);
+    out[0] = lay[0]; out[1] = lay[1]; out[2] = p.gen_cap;
+    return MRT_OK;
 }
 
 int mrt_debug_set_frames_in_flight(mrt_ctx* c, int slots) {

@@ -38,6 +38,8 @@
 #include "mrt_internal.h"
 #include "mrt_device.h"
 
+#include <type_traits>
+
 namespace mrt {
 namespace {
 
@@ -172,9 +174,10 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 // test's own rounding (4 eps |p|_1; the right-hand side's three roundings are in the extents).  A never-hit box has extents
 // -3e38: some axis' right-hand side is then hugely negative (a unit direction has a component >= 0.57).
 // 24 VALU: 3 + 3 (X) + 1 (K) + 3 x 5 + 2.
-__device__ __forceinline__ bool box_may_touch(const float4 b0, const float4 b1, V3 o, V3 d, bool quad) {
+template <bool QUAD>
+__device__ __forceinline__ bool box_may_touch(const float4 b0, const float4 b1, V3 o, V3 d) {
     const float px = o.x - b0.x, py = o.y - b0.y, pz = o.z - b0.z;
-    const float X = quad ? __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px))
+    const float X = QUAD ? __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px))
                          : (__builtin_fabsf(px) + __builtin_fabsf(py)) + __builtin_fabsf(pz);
     const float K = __builtin_fmaf(b1.z, X, b1.w);
     const float ex = b0.w, ey = b1.x, ez = b1.y;
@@ -315,13 +318,10 @@ constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 
 //   queue P.levels : (owner, top node)   written by the owners from their sweep masks
 //   queue k        : (owner, level-k node) whose bound the owner's ray may touch, 1 <= k < P.levels
 //   queue 0        : (owner, member)     members whose discriminant is >= 0, waiting for the root tests
-constexpr uint32_t kQueueCap = 320;       // < 64 left over + 4 x 64 pushed by one round (top queue: P.gen_cap)
-// Large scenes: the owners' candidates first go to a RAW top queue (P.gen_cap entries); filter rounds test each against the
-// node's box -- kFilterPerLane candidates per lane and round: a round's cost is mostly its chain of dependent reads (item ->
-// ray -> box from L2), which two independent chains share -- and move the survivors to the top queue proper, which then only
-// needs < 64 left over + 128 from one round.
-constexpr uint32_t kFilterPerLane = 2;
-constexpr uint32_t kFilteredCap = 64u * (kFilterPerLane + 1u);
+// (kQueueCap, mrt_internal.h: < 64 left over + 4 x 64 pushed by one round; the small scenes' top queue: P.gen_cap)
+// Large scenes keep ONE work stack of P.gen_cap entries for all inner levels (render_kernel) + this reserve: a round is sized
+// so that its pushes fit (<= 4 per item), down to one item per round, which may exceed the capacity by 3 entries per level
+// (kStackReserve, mrt_internal.h)
 constexpr unsigned long long kNoHitKey = 0x461C4000FFFFFFFFull;   // (bits(1e4f) << 32) | -1
 
 template <int N> struct IC { static constexpr int value = N; };
@@ -335,7 +335,7 @@ __host__ __device__ constexpr uint32_t lds_off_rays() { return 0u; }            
 __host__ __device__ constexpr uint32_t lds_off_ring() { return 2048u; }                // kRingCap x u32
 __host__ __device__ constexpr uint32_t lds_off_queues() { return 2048u + 512u; }
 __host__ __device__ constexpr uint32_t lds_queue_bytes(bool small, uint32_t levels, uint32_t gen_cap) {
-    return small ? (levels * kQueueCap + gen_cap) * 2u : (levels * kQueueCap + kFilteredCap + gen_cap) * 4u;
+    return small ? (levels * kQueueCap + gen_cap) * 2u : (gen_cap + kStackReserve + 3u * kQueueCap) * 4u;     // large: raw, cluster, root queues + the inner levels' stack
 }
 __host__ __device__ constexpr uint32_t lds_off_masks(bool small, uint32_t levels, uint32_t gen_cap) { return lds_off_queues() + lds_queue_bytes(small, levels, gen_cap); }
 __host__ __device__ constexpr uint32_t lds_wave_bytes(bool small, uint32_t levels, uint32_t gen_cap, uint32_t mask_chunks) {
@@ -395,17 +395,19 @@ constexpr uint32_t kWavesPerGroup = 4;
 // DBG (mrt_debug_world_hit): the same sweep + walk for caller-supplied rays instead of camera rays -- a lane's "pixel"
 // is ray number `texel` of P.dbg_rays, traced once; the winner goes to P.dbg_hit and every (ray, sphere) that
 // reaches the root tests is recorded in P.dbg_cand.  Nothing else of the kernel changes.
-template <bool COUNT, bool PILOT, bool CTR, bool SMALL, bool MFMA, bool DBG = false>
+// SC: the scene's layout -- 0 = SMALL (above), 1 / 2 = large, with the linear / the quadratic form of the box test's slack
+// (api.cpp build_boxes; a compile-time choice: as a run-time flag it was two branches in every box test).
+template <bool COUNT, bool PILOT, bool CTR, int SC, bool MFMA, bool DBG = false>
 // Registers: small scenes run 5 workgroups per CU (their LDS footprint, 31.5 KB at C3) = 5 waves per SIMD = 96 VGPRs; large
 // scenes (work queues of every level, u32 items: 33-36 KB per workgroup) fit 4 workgroups per CU whatever the kernel does, so
 // they may use the 128 VGPRs of 4 waves per SIMD instead of spilling at 96.
-__global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(SMALL ? 5 : 4, 8))) render_kernel(const KParams P) {
+__global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(SC == 0 ? 5 : 4, 8))) render_kernel(const KParams P) {
+    constexpr bool SMALL = SC == 0, QUAD = SC == 2;
     typedef typename Ent<SMALL>::type entry_t;
     constexpr uint32_t kIdBits = Ent<SMALL>::id_bits;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // small scenes always have one level (api.cpp): the queue bookkeeping below folds to two queues
-    constexpr int kLvMax = SMALL ? 1 : (int)kMaxLevels;
+    // small scenes always have one level (api.cpp)
     const uint32_t levels = SMALL ? 1u : P.levels;
     // (small scenes: the member records, then their sphere indices as u16 -- what a root round reads per item; from L2 the
     // index was a dependent global load in the middle of every root round)
@@ -646,251 +648,289 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 uint32_t wm = 0, ebase = 0;               // owner side: see the unpacking loop
                 uint32_t incl = wave_incl_scan(rem);
                 uint32_t total_rem = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                uint32_t qn[kLvMax + 1];
+                // owners unpack their masks into `n_new` (owner, top record) items at their scanned positions behind dst[0];
+                // wm: the 32-record mask word being unpacked (clz = record within the word); ebase: owner bits | first record
+                // id of that word.  `room` >= n_new entries are free behind dst.
+                auto unpack = [&](auto* const dst, const uint32_t room, const uint32_t owner_shift) -> uint32_t {
+                    typedef typename std::remove_pointer<decltype(dst)>::type item_t;
+                    const uint32_t excl = incl - rem;
+                    const uint32_t n_new = total_rem < room ? total_rem : room;
+                    item_t* wp = dst + excl;
+                    auto refill = [&]() {
+                        const uint32_t cc = (uint32_t)__builtin_ctz(nz);
+                        nz &= nz - 1u;
+                        wm = masks[cc * 64u];
+                        ebase = (lane << owner_shift) | (blk + cc * 2u * kChunk);
+                    };
+                    if (total_rem <= room) {             // the usual case: everything fits, no bound to watch
+                        while ((nz | wm) != 0u) {
+                            if (wm == 0u) refill();
+                            const uint32_t j = (uint32_t)__builtin_clz(wm);
+                            wm ^= 0x80000000u >> j;
+                            *wp++ = (item_t)(ebase + j);
+                            // further records of the same word in the same trip: fewer trips, i.e. fewer taken branches
 #pragma unroll
-                for (int lv = 0; lv <= kLvMax; lv++) qn[lv] = 0u;
-                // large scenes with boxes: the owners' candidates go to the RAW top queue first (behind the top queue proper,
-                // which is then kFilteredCap long); filter rounds move the ones whose box the ray's line touches on
-                uint32_t q_raw = 0;
-                const bool boxes = !SMALL && P.use_boxes != 0u;
-                constexpr int kRawLevel = kLvMax + 1;          // `k` of a filter round
-                for (;;) {
-                    // a full round at the deepest level that has one; else refill the top queue; else
-                    // a partial round at the highest level that has anything
-                    int k = -1;
-#pragma unroll
-                    for (int lv = 0; lv <= kLvMax; lv++) if (k < 0 && qn[lv] >= 64u) k = lv;
-                    if (!SMALL && k < 0 && q_raw >= 64u * kFilterPerLane) k = kRawLevel;
-                    if (k < 0) {
-                        if (total_rem != 0u) {
-                            // owners unpack their masks into (owner, cluster) items at their scanned positions
-                            const uint32_t excl = incl - rem;
-                            uint32_t n_top = 0;
-#pragma unroll
-                            for (int lv = 1; lv <= kLvMax; lv++) n_top = ((int)levels == lv) ? qn[lv] : n_top;
-                            if (boxes) n_top = q_raw;
-                            const uint32_t room = gen_cap - n_top;
-                            const uint32_t n_new = total_rem < room ? total_rem : room;
-                            entry_t* const dst = queues + levels * kQueueCap + (boxes ? kFilteredCap : 0u) + n_top;
-                            // wm: the 32-record mask word being unpacked (clz = record within the word);
-                            // ebase: owner bits | first record id of that word
-                            entry_t* wp = dst + excl;
-                            auto refill = [&]() {
-                                const uint32_t cc = (uint32_t)__builtin_ctz(nz);
-                                nz &= nz - 1u;
-                                wm = masks[cc * 64u];
-                                ebase = (lane << kIdBits) | (blk + cc * 2u * kChunk);
-                            };
-                            if (total_rem <= room) {             // the usual case: everything fits, no bound to watch
-                                while ((nz | wm) != 0u) {
-                                    if (wm == 0u) refill();
-                                    const uint32_t j = (uint32_t)__builtin_clz(wm);
-                                    wm ^= 0x80000000u >> j;
-                                    *wp++ = (entry_t)(ebase + j);
-                                    // further records of the same word in the same trip: fewer trips, i.e. fewer taken branches
-#pragma unroll
-                                    for (int more = 0; more < kUnpackMore; more++) {
-                                        if (wm != 0u) {
-                                            const uint32_t j2 = (uint32_t)__builtin_clz(wm);
-                                            wm ^= 0x80000000u >> j2;
-                                            *wp++ = (entry_t)(ebase + j2);
-                                        }
-                                    }
-                                }
-                            } else {
-                                entry_t* const wend = dst + n_new;
-                                while ((nz | wm) != 0u && wp < wend) {
-                                    if (wm == 0u) refill();
-                                    const uint32_t j = (uint32_t)__builtin_clz(wm);
-                                    wm ^= 0x80000000u >> j;
-                                    *wp++ = (entry_t)(ebase + j);
+                            for (int more = 0; more < kUnpackMore; more++) {
+                                if (wm != 0u) {
+                                    const uint32_t j2 = (uint32_t)__builtin_clz(wm);
+                                    wm ^= 0x80000000u >> j2;
+                                    *wp++ = (item_t)(ebase + j2);
                                 }
                             }
-                            rem -= (uint32_t)(wp - (dst + excl));
-                            if (boxes) q_raw += n_new;
-                            else {
-#pragma unroll
-                                for (int lv = 1; lv <= kLvMax; lv++) if ((int)levels == lv) qn[lv] += n_new;
-                            }
-                            total_rem -= n_new;
-                            if (total_rem != 0u) incl = wave_incl_scan(rem);
-                            lds_order();
-                            MRT_STAMP(6);
-                            continue;
                         }
-                        if (!SMALL && q_raw != 0u) k = kRawLevel;
-#pragma unroll
-                        for (int lv = kLvMax; lv >= 0; lv--) if (k < 0 && qn[lv] != 0u) k = lv;
-                        if (k < 0) break;
+                    } else {
+                        item_t* const wend = dst + n_new;
+                        while ((nz | wm) != 0u && wp < wend) {
+                            if (wm == 0u) refill();
+                            const uint32_t j = (uint32_t)__builtin_clz(wm);
+                            wm ^= 0x80000000u >> j;
+                            *wp++ = (item_t)(ebase + j);
+                        }
                     }
-                    if (!SMALL && k == kRawLevel) {
-                        // filter round: up to 128 raw candidates (owner, top node), two per lane: does the owner's line touch
-                        // the node's box?  The survivors move to the top queue proper.  (7.2 -> 1.9 items per ray at C5.)
-                        constexpr uint32_t kPer = kFilterPerLane;
-                        const uint32_t take = q_raw < 64u * kPer ? q_raw : 64u * kPer, start = q_raw - take;
-                        const entry_t* const src = queues + levels * kQueueCap + kFilteredCap;
-                        const KArgPtr C = cold_args();
-                        const float4* const bxs = reinterpret_cast<const float4*>(C->boxes) + 2u * (size_t)C->box_top;
-                        const bool quad = C->box_quad != 0u;
-                        uint32_t it[kPer];
-                        bool keep[kPer];
-                        unsigned long long km[kPer];
-#pragma unroll
-                        for (uint32_t q = 0; q < kPer; q++) it[q] = src[(lane + 64u * q < take) ? start + lane + 64u * q : 0u];
-#pragma unroll
-                        for (uint32_t q = 0; q < kPer; q++) {
-                            const uint32_t owner = it[q] >> kIdBits, node = it[q] & ((1u << kIdBits) - 1u);
-                            const float4 r0 = rays[2u * owner];
-                            const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
-                            const float4* const bx = bxs + 2u * (size_t)node;
-                            keep[q] = (lane + 64u * q < take) && box_may_touch(bx[0], bx[1], v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), quad);
-                            km[q] = __builtin_amdgcn_ballot_w64(keep[q]);
-                        }
-                        uint32_t n_top = 0;
-#pragma unroll
-                        for (int lv = 1; lv <= kLvMax; lv++) n_top = ((int)levels == lv) ? qn[lv] : n_top;
-                        uint32_t kept = 0;
-#pragma unroll
-                        for (uint32_t q = 0; q < kPer; q++) {
-                            if (keep[q]) queues[levels * kQueueCap + n_top + kept + rank_in(km[q])] = (entry_t)it[q];
-                            kept += (uint32_t)__popcll(km[q]);
-                        }
-#pragma unroll
-                        for (int lv = 1; lv <= kLvMax; lv++) if ((int)levels == lv) qn[lv] += kept;
-                        q_raw = start;
-                        lds_order();
-                        MRT_STAMP(2);           // (the stamps build books filter rounds under the node rounds' time)
-                        continue;
-                    }
-                    // One round at level K, K a compile-time constant in each copy: the queue counters are plain registers and
-                    // the level-dependent choices (stretch, `a`, the children's base) fold away.  (With the level a run-time
-                    // value every access was a chain of selects over the levels -- half the instructions of a large scene's
-                    // round.)
-                    auto round_at = [&](auto KC) {
-                    constexpr int K = decltype(KC)::value;
-                    const uint32_t n = qn[K];
+                    rem -= (uint32_t)(wp - (dst + excl));
+                    total_rem -= n_new;
+                    if (total_rem != 0u) incl = wave_incl_scan(rem);
+                    lds_order();
+                    MRT_STAMP(6);
+                    return n_new;
+                };
+                // root round: the reference's sqrt / divide / range tests (shader.wgsl:286-296) for up to 64 (owner, member)
+                // items.  Each member's root goes into its owner's slot by a 64-bit unsigned minimum of
+                // (bits(t) << 32 | sphere index): t > 0, so this is the lexicographic minimum of (t, index) over spheres with
+                // a root in [0.001, 1e4) -- what the reference's index-order scan with `t_sup <= t` (:291-296) ends with
+                // (`near` is tried first, `far` only if `near` is out of range: near >= t_sup implies far >= t_sup).
+                auto root_round = [&](const entry_t* const src, uint32_t& n) {
                     const uint32_t take = n < 64u ? n : 64u, start = n - take;
                     const bool act = lane < take;
-                    const entry_t* const src = queues + (uint32_t)K * kQueueCap;
                     const uint32_t it = src[act ? start + lane : 0u];
                     const uint32_t owner = it >> kIdBits, node = it & ((1u << kIdBits) - 1u);
                     const float4 r0 = rays[2u * owner];
                     const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
                     const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r0.w, r1.x, r1.y);
                     const float ra = dot3(rd, rd);                      // the owner's `a`, same expression
-                    if constexpr (K != 0) {
-                        // node round, 4 children per item.  k == 1: the reference's discriminant (shader.wgsl:274-282)
-                        // for the cluster's members; members with disc >= 0 become (owner, member) items.
-                        // k >= 2: the sweep's conservative test on the child bounds (the same expression with
-                        // the direction stretched and a = 1, bit for bit test1()); passing children become items.
+                    const SphereRec sm = nodes[node];
+                    const uint32_t sidx = SMALL ? (uint32_t)index_lds[node] : member_index[node];
+                    const float ocx = ro.x - sm.cx, ocy = ro.y - sm.cy, ocz = ro.z - sm.cz;
+                    const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
+                    const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sm.neg_r2)));
+                    const float disc = __builtin_fmaf(bq, bq, -(ra * cq));
+                    // sqrt and the two divisions by `ra` without operand scaling: ra is within 1e-5 of 1 (`weird` rays
+                    // own no items), so scaling could only act on a numerator below 2^-102 or above 2^95 -- roots that
+                    // fail the range test below whatever their last bits -- and on disc < 2^-96, a d_sqrt below 2^-47
+                    // that changes -bq -+ d_sqrt only where that sum is below 2^-19 < t_min.
+                    const float d_sqrt = sqrt_unscaled(disc);                     // :286
+                    const float t_min = 0.001f;                                   // :340
+                    const Divisor by_a = divisor_of(ra);
+                    const float t_near = div_unscaled(-bq - d_sqrt, by_a);        // :290
+                    const float t_far = div_unscaled(-bq + d_sqrt, by_a);         // :292
+                    const bool ok_near = !(t_near < t_min) && t_near < 1.0e4f;
+                    const bool ok_far = !(t_far < t_min) && t_far < 1.0e4f;
+                    const float t = ok_near ? t_near : t_far;
+                    // (unconditional, with a key that changes nothing for lanes without a root: no branch
+                    // for the index load to hide behind)
+                    const unsigned long long key = (act && (ok_near || ok_far)) ? (((unsigned long long)__float_as_uint(t) << 32) | sidx) : kNoHitKey;
+                    atomicMin(best_slots + 4u * owner, key);
+                    if (DBG) {      // this (ray, sphere) passed the sweep, the walk and the exact discriminant
+                        const uint32_t owner_ray = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)texel);
+                        if (act) atomicOr(P.dbg_cand + (size_t)owner_ray * P.dbg_words + (sidx >> 5), 1u << (sidx & 31u));
+                    }
+                    n = start;
+#ifdef MRT_STAMPS
+                    rounds_b_++; items_b_ += take;
+#endif
+                    lds_order();
+                    MRT_STAMP(3);
+                };
+                // The reference's discriminant (shader.wgsl:274-282) for the 4 members of a cluster; members with disc >= 0
+                // become (owner, member) items at dst[dn ..].  A member that lies entirely behind the ray's origin -- origin
+                // outside it (cq >= 0) and its centre not ahead (bq >= 0): then sqrt(disc) <= bq, both roots of :290-292 are
+                // <= 0 and fail t >= 0.001 (:291) -- can never be the hit and is dropped here.  Both conditions from sign
+                // bits, in one three-input bit operation and one comparison: the discriminant of a finite ray against finite
+                // geometry is never NaN, and never -0 (b*b - a*c cancels to +0), so "not < 0" is "sign bit clear".
+                // `on`: the lanes whose item this is; returns the number of items pushed.
+                auto members_round = [&](const SphereRec* const ch, const V3 ro, const V3 rd, const float ra, const bool on,
+                                         const uint32_t e0, entry_t* const dst) -> uint32_t {
+                    const SphereRec sr[4] = {ch[0], ch[1], ch[2], ch[3]};
+                    bool h[4];
+                    unsigned long long hm[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float ocx = ro.x - sr[q].cx, ocy = ro.y - sr[q].cy, ocz = ro.z - sr[q].cz;
+                        const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
+                        const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sr[q].neg_r2)));
+                        const float disc = __builtin_fmaf(bq, bq, -(ra * cq));
+                        h[q] = (int32_t)((__float_as_uint(bq) | __float_as_uint(cq)) & ~__float_as_uint(disc)) < 0;
+                        hm[q] = __builtin_amdgcn_ballot_w64(h[q]);
+                    }
+                    const unsigned long long on_mask = __builtin_amdgcn_ballot_w64(on);
+                    const unsigned long long m0 = hm[0] & on_mask, m1 = hm[1] & on_mask, m2 = hm[2] & on_mask, m3 = hm[3] & on_mask;
+                    // About one member in twenty passes (C3: 43 of 868 per world_hit), so a lane hardly ever holds two: when none
+                    // does -- decided on the scalar side -- ONE ranked push serves the round instead of four.
+                    const unsigned long long any = m0 | m1 | m2 | m3;
+                    const unsigned long long twice = (m0 & m1) | ((m0 | m1) & m2) | ((m0 | m1 | m2) & m3);
+                    if (twice == 0ull) {
+                        const uint32_t q = h[1] ? 1u : h[2] ? 2u : h[3] ? 3u : 0u;
+                        if ((h[0] || h[1] || h[2] || h[3]) && on) dst[rank_in(any)] = (entry_t)(e0 + q);
+                        return (uint32_t)__popcll(any);
+                    }
+                    uint32_t pushed = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const unsigned long long mk = hm[q] & on_mask;
+                        if (h[q] && on) dst[pushed + rank_in(mk)] = (entry_t)(e0 + (uint32_t)q);
+                        pushed += (uint32_t)__popcll(mk);
+                    }
+                    return pushed;
+                };
+                if constexpr (SMALL) {
+                    // Small scenes (one level): queue 1 = (owner, cluster) from the owners' masks, queue 0 = (owner, member)
+                    // waiting for the root tests.  A full round at the deeper queue that has one; else refill queue 1; else
+                    // a partial round at queue 1, then queue 0.
+                    uint32_t qn0 = 0, qn1 = 0;
+                    entry_t* const q0 = queues, * const q1 = queues + kQueueCap;
+                    for (;;) {
+                        int k = qn0 >= 64u ? 0 : qn1 >= 64u ? 1 : -1;
+                        if (k < 0) {
+                            if (total_rem != 0u) { qn1 += unpack(q1 + qn1, gen_cap - qn1, kIdBits); continue; }
+                            k = qn1 != 0u ? 1 : qn0 != 0u ? 0 : -1;
+                            if (k < 0) break;
+                        }
+                        if (k == 0) { root_round(q0, qn0); continue; }
+                        // node round: 64 lanes take the last 64 (owner, cluster) items, whoever owns them
                         // (Round 1 rotated the four reads by node/4 to spread one read's 64 lanes over all LDS banks; the 8
                         // VALU of address arithmetic per round cost more than the bank conflicts they avoided: round 2.)
-                        constexpr bool inner = K >= 2;
-                        const float sc = inner ? kBoundStretch : 1.0f, ra_eff = inner ? 1.0f : ra;
-                        const V3 re = v3(rd.x * sc, rd.y * sc, rd.z * sc);
-                        const uint32_t cbase = K >= 2 ? P.level_base[K >= 2 ? K - 1 : 0] : 0u;      // first record of the children's level
-                        const SphereRec* const ch = nodes + cbase + 4u * node;
-                        bool h[4];
-                        unsigned long long hm[4];
-                        if (!SMALL && inner && boxes) {
-                            // large scenes: the children's boxes instead of their bounding spheres
-                            const KArgPtr C = cold_args();
-                            const float4* const bx = reinterpret_cast<const float4*>(C->boxes) + 2u * (size_t)(C->box_base[inner ? K - 1 : 0] + 4u * node);
-                            const bool quad = C->box_quad != 0u;
-                            const float4 b[8] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], bx[6], bx[7]};
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                h[q] = box_may_touch(b[2 * q], b[2 * q + 1], ro, rd, quad);
-                                hm[q] = __builtin_amdgcn_ballot_w64(h[q]);
-                            }
-                        } else {
-                            const SphereRec sr[4] = {ch[0], ch[1], ch[2], ch[3]};
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const float ocx = ro.x - sr[q].cx, ocy = ro.y - sr[q].cy, ocz = ro.z - sr[q].cz;
-                                const float bq = __builtin_fmaf(ocz, re.z, __builtin_fmaf(ocy, re.y, ocx * re.x));
-                                const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sr[q].neg_r2)));
-                                const float disc = __builtin_fmaf(bq, bq, -(ra_eff * cq));
-                                // A child whose sphere lies entirely behind the ray's origin -- origin outside it (cq >= 0)
-                                // and its centre not ahead (bq >= 0): then sqrt(disc) <= bq, both roots of :290-292 are <= 0
-                                // and fail t >= 0.001 (:291) -- can never be the hit; for a bound (1.5 % larger than what it
-                                // encloses) the same holds for everything inside it.  Dropping it here saves its root test /
-                                // its subtree; it does not change the winner.  Sign bits: both >= +0.
-                                // Both conditions from sign bits, in one three-input bit operation and one comparison: the
-                                // discriminant of a finite ray against finite geometry is never NaN, and never -0 (b*b - a*c
-                                // cancels to +0), so "not < 0" is "sign bit clear".
-                                h[q] = (int32_t)((__float_as_uint(bq) | __float_as_uint(cq)) & ~__float_as_uint(disc)) < 0;
-                                hm[q] = __builtin_amdgcn_ballot_w64(h[q]);
-                            }
-                        }
-                        const uint32_t dn = qn[K - 1];
-                        entry_t* const dst = queues + (uint32_t)(K - 1) * kQueueCap + dn;
-                        const uint32_t e0 = (owner << kIdBits) | (4u * node);
-                        uint32_t pushed = 0;
-                        const unsigned long long act_mask = take >= 64u ? ~0ull : ((1ull << take) - 1ull);
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const unsigned long long mk = hm[q] & act_mask;
-                            if (h[q] && act) dst[pushed + rank_in(mk)] = (entry_t)(e0 + (uint32_t)q);
-                            pushed += (uint32_t)__popcll(mk);
-                        }
-                        qn[K] = start;
-                        qn[K - 1] += pushed;
-                        if (!PILOT && K == 1) mtests += kClusterK * take;
+                        const uint32_t take = qn1 < 64u ? qn1 : 64u, start = qn1 - take;
+                        const bool act = lane < take;
+                        const uint32_t it = q1[act ? start + lane : 0u];
+                        const uint32_t owner = it >> kIdBits, node = it & ((1u << kIdBits) - 1u);
+                        const float4 r0 = rays[2u * owner];
+                        const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
+                        const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r0.w, r1.x, r1.y);
+                        qn0 += members_round(nodes + 4u * node, ro, rd, dot3(rd, rd), act, (owner << kIdBits) | (4u * node), q0 + qn0);
+                        qn1 = start;
+                        if (!PILOT) mtests += kClusterK * take;
 #ifdef MRT_STAMPS
                         rounds_a_++; items_a_ += take;
 #endif
                         lds_order();
                         MRT_STAMP(2);
-                    } else {
-                        // root round: the reference's sqrt / divide / range tests (shader.wgsl:286-296).
-                        // Each member's root goes into its owner's slot by a 64-bit unsigned minimum of
-                        // (bits(t) << 32 | sphere index): t > 0, so this is the lexicographic minimum of
-                        // (t, index) over spheres with a root in [0.001, 1e4) -- what the reference's
-                        // index-order scan with `t_sup <= t` (:291-296) ends with (`near` is tried first,
-                        // `far` only if `near` is out of range: near >= t_sup implies far >= t_sup).
-                        const SphereRec sm = nodes[node];
-                        const uint32_t sidx = SMALL ? (uint32_t)index_lds[node] : member_index[node];
-                        const float ocx = ro.x - sm.cx, ocy = ro.y - sm.cy, ocz = ro.z - sm.cz;
-                        const float bq = __builtin_fmaf(ocz, rd.z, __builtin_fmaf(ocy, rd.y, ocx * rd.x));
-                        const float cq = __builtin_fmaf(ocz, ocz, __builtin_fmaf(ocy, ocy, __builtin_fmaf(ocx, ocx, sm.neg_r2)));
-                        const float disc = __builtin_fmaf(bq, bq, -(ra * cq));
-                        // sqrt and the two divisions by `ra` without operand scaling: ra is within 1e-5 of 1 (`weird` rays
-                        // own no items), so scaling could only act on a numerator below 2^-102 or above 2^95 -- roots that
-                        // fail the range test below whatever their last bits -- and on disc < 2^-96, a d_sqrt below 2^-47
-                        // that changes -bq -+ d_sqrt only where that sum is below 2^-19 < t_min.
-                        const float d_sqrt = sqrt_unscaled(disc);                     // :286
-                        const float t_min = 0.001f;                                   // :340
-                        const Divisor by_a = divisor_of(ra);
-                        const float t_near = div_unscaled(-bq - d_sqrt, by_a);        // :290
-                        const float t_far = div_unscaled(-bq + d_sqrt, by_a);         // :292
-                        const bool ok_near = !(t_near < t_min) && t_near < 1.0e4f;
-                        const bool ok_far = !(t_far < t_min) && t_far < 1.0e4f;
-                        const float t = ok_near ? t_near : t_far;
-                        // (unconditional, with a key that changes nothing for lanes without a root: no branch
-                        // for the index load to hide behind)
-                        const unsigned long long key = (act && (ok_near || ok_far)) ? (((unsigned long long)__float_as_uint(t) << 32) | sidx) : kNoHitKey;
-                        atomicMin(best_slots + 4u * owner, key);
-                        if (DBG) {      // this (ray, sphere) passed the sweep, the walk and the exact discriminant
-                            const uint32_t owner_ray = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)texel);
-                            if (act) atomicOr(P.dbg_cand + (size_t)owner_ray * P.dbg_words + (sidx >> 5), 1u << (sidx & 31u));
+                    }
+                } else {
+                    // Large scenes.  Four queues, deepest first:
+                    //   raw      (owner, top record j) from the owners' masks: does the owner's line touch the record's BOX (the
+                    //            sweep tested its bounding sphere)?  Filter rounds, two items per lane (a filter round is
+                    //            mostly its chain of dependent reads item -> ray -> box, which two independent chains share).
+                    //   inner    ONE stack for every level below the top: (owner, node g), g numbered top-down over the complete
+                    //            4-ary tree (children of g = 4 g + P.n_padded .. + 3, whatever the level): test the 4 children's
+                    //            boxes.  A round takes the last 64 items whatever their levels -- the code is the same -- so that
+                    //            the three inner levels of C5 end a world_hit with ONE partial round instead of three.
+                    //   cluster  (owner, cluster-level node g): the reference's discriminant for the cluster's 4 members
+                    //            (level 0, members 4 m .. 4 m + 3, m = g - P.box_cluster_first)
+                    //   root     (owner, member): the root tests
+                    // A full round at the deepest queue that has one; else unpack more candidates; else a partial round at the
+                    // HIGHEST queue that holds anything (what it pushes may still fill the queues below).
+                    constexpr uint32_t kPer = 2u, kIndexMask = (1u << 26) - 1u;
+                    uint32_t n_raw = 0, sn = 0, cn = 0, rn = 0;
+                    uint32_t* const rawq = queues;                                    // kQueueCap entries
+                    uint32_t* const clusterq = queues + kQueueCap;                    // kQueueCap
+                    uint32_t* const rootq = queues + 2u * kQueueCap;                  // kQueueCap
+                    uint32_t* const stack = queues + 3u * kQueueCap;                  // gen_cap + kStackReserve
+                    const float4* const bxs = reinterpret_cast<const float4*>(P.boxes);
+                    const uint32_t cluster_parent_first = P.box_cluster_parent_first;
+                    for (;;) {
+                        int k = rn >= 64u ? 0 : cn >= 64u ? 1 : sn >= 64u ? 2 : n_raw >= 64u * kPer ? 3 : -1;
+                        if (k < 0) {
+                            if (total_rem != 0u && n_raw < kQueueCap) { n_raw += unpack(rawq + n_raw, kQueueCap - n_raw, 26u); continue; }
+                            k = n_raw != 0u ? 3 : sn != 0u ? 2 : cn != 0u ? 1 : rn != 0u ? 0 : -1;
+                            if (k < 0) break;
                         }
-                        qn[0] = start;
+                        if (k == 0) { root_round(rootq, rn); continue; }
+                        if (k == 3) {
+                            // filter round: up to 128 raw candidates, two per lane; the survivors become inner items (top
+                            // record j = node j) -- or cluster items where the top IS the cluster level (a one-level hierarchy)
+                            const uint32_t take = n_raw < 64u * kPer ? n_raw : 64u * kPer, start = n_raw - take;
+                            uint32_t it[kPer];
+                            bool keep[kPer];
+                            unsigned long long km[kPer];
+#pragma unroll
+                            for (uint32_t q = 0; q < kPer; q++) it[q] = rawq[(lane + 64u * q < take) ? start + lane + 64u * q : 0u];
+#pragma unroll
+                            for (uint32_t q = 0; q < kPer; q++) {
+                                const uint32_t owner = it[q] >> 26, node = it[q] & kIndexMask;
+                                const float4 r0 = rays[2u * owner];
+                                const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
+                                const float4* const bx = bxs + 2u * (size_t)node;
+                                keep[q] = box_may_touch<QUAD>(bx[0], bx[1], v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y)) && (lane + 64u * q < take);
+                                km[q] = __builtin_amdgcn_ballot_w64(keep[q]);
+                            }
+                            uint32_t* const dst = levels == 1u ? clusterq + cn : stack + sn;
+                            uint32_t kept = 0;
+#pragma unroll
+                            for (uint32_t q = 0; q < kPer; q++) {
+                                if (keep[q]) dst[kept + rank_in(km[q])] = it[q];
+                                kept += (uint32_t)__popcll(km[q]);
+                            }
+                            if (levels == 1u) cn += kept; else sn += kept;
+                            n_raw = start;
+                            lds_order();
+                            MRT_STAMP(2);           // (the stamps build books filter rounds under the node rounds' time)
+                            continue;
+                        }
+                        const uint32_t n = k == 1 ? cn : sn;
+                        uint32_t take = n < 64u ? n : 64u;
+                        if (k == 2) {
+                            // an inner round pushes at most 4 items per item it pops: never beyond the stack (+ its reserve)
+                            const uint32_t fit = gen_cap > sn ? (gen_cap - sn) / 3u : 0u;
+                            take = take <= fit ? take : (fit ? fit : 1u);
+                        }
+                        const uint32_t start = n - take;
+                        const bool act = lane < take;
+                        const uint32_t it = (k == 1 ? clusterq : stack)[act ? start + lane : 0u];
+                        const uint32_t owner = it >> 26, g = act ? it & kIndexMask : 0u;
+                        const float4 r0 = rays[2u * owner];
+                        const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
+                        const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r0.w, r1.x, r1.y);
+                        if (k == 1) {
+                            const uint32_t m4 = act ? 4u * (g - P.box_cluster_first) : 0u;
+                            rn += members_round(nodes + m4, ro, rd, dot3(rd, rd), act, (owner << 26) | m4, rootq + rn);
+                            cn = start;
+                            if (!PILOT) mtests += kClusterK * take;
+                        } else {
+                            const uint32_t c0 = 4u * g + n_padded;                    // the first child, in the same numbering
+                            const float4* const bx = bxs + 2u * (size_t)c0;
+                            const float4 b[8] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], bx[6], bx[7]};
+                            bool h[4];
+                            unsigned long long hm[4];
+                            const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(act);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                h[q] = box_may_touch<QUAD>(b[2 * q], b[2 * q + 1], ro, rd);
+                                hm[q] = __builtin_amdgcn_ballot_w64(h[q]) & act_mask;
+                            }
+                            sn = start;
+                            // the children of a node of the level above the clusters are clusters: they go to the cluster queue,
+                            // the others back on the stack.  A round is mostly of one level (children arrive on top in bulk)
+                            const bool to_c = g >= cluster_parent_first;
+                            const unsigned long long m_c = __builtin_amdgcn_ballot_w64(to_c) & act_mask, m_s = act_mask & ~m_c;
+                            const uint32_t e0 = (owner << 26) | c0;
+                            auto push4 = [&](uint32_t* const dst, const unsigned long long who, const bool mine) -> uint32_t {
+                                uint32_t pushed = 0;
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    const unsigned long long mk = hm[q] & who;
+                                    if (h[q] && mine) dst[pushed + rank_in(mk)] = e0 + (uint32_t)q;
+                                    pushed += (uint32_t)__popcll(mk);
+                                }
+                                return pushed;
+                            };
+                            if (m_s != 0ull) sn += push4(stack + sn, m_s, act && !to_c);
+                            if (m_c != 0ull) cn += push4(clusterq + cn, m_c, act && to_c);
+                        }
 #ifdef MRT_STAMPS
-                        rounds_b_++; items_b_ += take;
+                        rounds_a_++; items_a_ += take;
 #endif
                         lds_order();
-                        MRT_STAMP(3);
-                    }
-                    };
-                    if (k == 0) round_at(IC<0>{});
-                    else if (kLvMax == 1 || k == 1) round_at(IC<1>{});
-                    else if constexpr (kLvMax >= 2) {
-                        if (k == 2) round_at(IC<2>{});
-                        else if constexpr (kLvMax >= 3) {
-                            if (k == 3) round_at(IC<3>{});
-                            else if constexpr (kLvMax >= 4) round_at(IC<4>{});
-                        }
+                        MRT_STAMP(2);
                     }
                 }
             }
@@ -1262,6 +1302,23 @@ static uint32_t group_lds_bytes(const KParams& p, bool small) {
            kWavesPerGroup * lds_wave_bytes(small, p.levels, p.gen_cap, p.mask_chunks);
 }
 
+// host: LDS bytes of one workgroup and how many of them one CU holds, for this scene's layout (launch sizing; pinned by
+// tests/test_hierarchy_host.py so that a change of the layout cannot drop residency unnoticed)
+void render_lds_layout(const KParams& p, uint32_t out[2]) {
+    const bool small = scene_is_small(p);
+    const uint32_t lds = group_lds_bytes(p, small);
+    uint32_t per_cu = (160u * 1024u) / lds;
+    if (!small && per_cu > 4u) per_cu = 4u;         // the large-scene kernels are built for 4 waves per SIMD (render_kernel)
+    out[0] = lds;
+    out[1] = per_cu;
+}
+// the wave's work-stack capacity that makes a large scene's workgroup fit 4 per CU (160 KB / 4 groups / 4 waves per wave)
+uint32_t large_scene_stack_cap(uint32_t mask_chunks) {
+    const uint32_t budget = 160u * 1024u / 4u / kWavesPerGroup;
+    const uint32_t fixed = lds_off_queues() + (kStackReserve + 3u * kQueueCap) * 4u + mask_chunks * 128u;
+    return (budget - fixed) / 4u;
+}
+
 // the persistent render waves (pilot: + its cost-only finalize) on `stream`
 int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream, uint32_t* which) {
     if (which) *which = 0xFFFFFFFFu;
@@ -1269,28 +1326,31 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream, 
     hipStream_t st = (hipStream_t)stream;
     // (the queue counter is zero: reset at allocation and by every finalize pass of the slot)
     const bool small = scene_is_small(p);
-    const uint32_t lds = group_lds_bytes(p, small);
     // persistent grid: as many workgroups as are resident with this launch's LDS footprint
     // (n_waves comes from the register-limited occupancy)
+    uint32_t lay[2];
+    render_lds_layout(p, lay);
+    const uint32_t lds = lay[0];
     {
-        uint32_t per_cu = (160u * 1024u) / lds;
-        if (!small && per_cu > 4u) per_cu = 4u;         // the large-scene kernels are built for 4 waves per SIMD (render_kernel)
-        const uint32_t cap = p.cus * per_cu * kWavesPerGroup;
+        const uint32_t cap = p.cus * lay[1] * kWavesPerGroup;
         if (cap < n_waves) n_waves = cap;
     }
     const uint32_t want = n_waves < p.n_tiles ? n_waves : p.n_tiles;
     dim3 grid((want + kWavesPerGroup - 1) / kWavesPerGroup), block(64 * kWavesPerGroup);
     const bool ctr = p.locals.rng_mode == MRT_RNG_COUNTER;
-    const bool mfma = p.use_mfma != 0;
+    const bool mfma = p.use_mfma != 0, quad = p.box_quad != 0;
 #define MRT_LAUNCH(C_, P_, R_)                                                                                      \
     do {                                                                                                            \
-        if (small && mfma) hipLaunchKernelGGL((render_kernel<C_, P_, R_, true, true>), grid, block, lds, st, p);    \
-        else if (small) hipLaunchKernelGGL((render_kernel<C_, P_, R_, true, false>), grid, block, lds, st, p);      \
-        else if (mfma) hipLaunchKernelGGL((render_kernel<C_, P_, R_, false, true>), grid, block, lds, st, p);       \
-        else hipLaunchKernelGGL((render_kernel<C_, P_, R_, false, false>), grid, block, lds, st, p);                \
+        if (small && mfma) hipLaunchKernelGGL((render_kernel<C_, P_, R_, 0, true>), grid, block, lds, st, p);       \
+        else if (small) hipLaunchKernelGGL((render_kernel<C_, P_, R_, 0, false>), grid, block, lds, st, p);         \
+        else if (quad && mfma) hipLaunchKernelGGL((render_kernel<C_, P_, R_, 2, true>), grid, block, lds, st, p);   \
+        else if (quad) hipLaunchKernelGGL((render_kernel<C_, P_, R_, 2, false>), grid, block, lds, st, p);          \
+        else if (mfma) hipLaunchKernelGGL((render_kernel<C_, P_, R_, 1, true>), grid, block, lds, st, p);           \
+        else hipLaunchKernelGGL((render_kernel<C_, P_, R_, 1, false>), grid, block, lds, st, p);                    \
     } while (0)
-    // which instantiation this is, for mrt_debug_last_launch: bit 0 COUNT, 1 PILOT, 2 CTR, 3 SMALL, 4 MFMA
-    if (which) *which = ((!pilot && p.count_draws) ? 1u : 0u) | (pilot ? 2u : 0u) | (ctr ? 4u : 0u) | (small ? 8u : 0u) | (mfma ? 16u : 0u);
+    // which instantiation this is, for mrt_debug_last_launch: bit 0 COUNT, 1 PILOT, 2 CTR, 3 SMALL, 4 MFMA, 5 quadratic box slack
+    if (which) *which = ((!pilot && p.count_draws) ? 1u : 0u) | (pilot ? 2u : 0u) | (ctr ? 4u : 0u) | (small ? 8u : 0u) | (mfma ? 16u : 0u) |
+                        ((!small && quad) ? 32u : 0u);
     if (pilot) {
         if (ctr) MRT_LAUNCH(false, true, true); else MRT_LAUNCH(false, true, false);
         hipLaunchKernelGGL((finalize_kernel<true>), dim3(p.n_tiles), dim3(64), 0, st, p);
@@ -1312,18 +1372,21 @@ int launch_debug_world_hit(const KParams& p, uint32_t n_waves, void* stream) {
     hipError_t e = hipMemsetAsync(p.tile_queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return (int)e;
     const bool small = scene_is_small(p);
-    const uint32_t lds = group_lds_bytes(p, small);
-    uint32_t per_cu = (160u * 1024u) / lds;
-    if (!small && per_cu > 4u) per_cu = 4u;
-    const uint32_t cap = p.cus * per_cu * kWavesPerGroup;
+    uint32_t lay[2];
+    render_lds_layout(p, lay);
+    const uint32_t lds = lay[0];
+    const uint32_t cap = p.cus * lay[1] * kWavesPerGroup;
     if (cap < n_waves) n_waves = cap;
     const uint32_t want = n_waves < p.n_tiles ? n_waves : p.n_tiles;
     dim3 grid((want + kWavesPerGroup - 1) / kWavesPerGroup), block(64 * kWavesPerGroup);
     const bool mfma = p.use_mfma != 0;
-    if (small && mfma) hipLaunchKernelGGL((render_kernel<false, false, false, true, true, true>), grid, block, lds, st, p);
-    else if (small) hipLaunchKernelGGL((render_kernel<false, false, false, true, false, true>), grid, block, lds, st, p);
-    else if (mfma) hipLaunchKernelGGL((render_kernel<false, false, false, false, true, true>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((render_kernel<false, false, false, false, false, true>), grid, block, lds, st, p);
+    const bool quad = p.box_quad != 0;
+    if (small && mfma) hipLaunchKernelGGL((render_kernel<false, false, false, 0, true, true>), grid, block, lds, st, p);
+    else if (small) hipLaunchKernelGGL((render_kernel<false, false, false, 0, false, true>), grid, block, lds, st, p);
+    else if (quad && mfma) hipLaunchKernelGGL((render_kernel<false, false, false, 2, true, true>), grid, block, lds, st, p);
+    else if (quad) hipLaunchKernelGGL((render_kernel<false, false, false, 2, false, true>), grid, block, lds, st, p);
+    else if (mfma) hipLaunchKernelGGL((render_kernel<false, false, false, 1, true, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((render_kernel<false, false, false, 1, false, true>), grid, block, lds, st, p);
     return (int)hipGetLastError();
 }
 
@@ -1337,7 +1400,7 @@ int launch_finalize(const KParams& p, void* stream) {
 // how many waves of the render kernel one CU holds (occupancy API)
 int render_waves_per_cu(int* out) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false, false, false, false>, 64 * kWavesPerGroup, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<true, false, false, 1, false>, 64 * kWavesPerGroup, 0);
     *out = nb * (int)kWavesPerGroup;
     return (int)e;
 }

@@ -34,10 +34,13 @@ struct mrt_ctx {
     float* d_shade = nullptr;              // 8 floats per sphere: centre, radius, material colour, fuzz | ior
     mrt::SphereRec* d_nodes = nullptr;     // hierarchy levels below the top: members (kClusterK per cluster), clusters, ...
     uint32_t* d_member_index = nullptr;    // their indices in the reference's sphere order
-    mrt::BoxRec* d_boxes = nullptr;        // axis-aligned boxes of the nodes of levels 1 .. top (large scenes' walk)
-    uint32_t box_base[mrt::kMaxLevels + 1] = {0, 0, 0, 0, 0};
+    // large scenes' walk: the axis-aligned boxes of the hierarchy's nodes in the kernel's top-down numbering (KParams::boxes),
+    // and the same array with every real box opened wide (a box test that never rejects: mrt_debug_set_boxes(0))
+    mrt::BoxRec* d_boxes = nullptr;
+    mrt::BoxRec* d_boxes_open = nullptr;
+    uint32_t box_cluster_first = 0, box_cluster_parent_first = 0;
     bool box_quad = false;
-    int boxes_mode = 1;                    // mrt_debug_set_boxes: 0 never, 1 automatic (beyond 4,096 member slots), 2 whenever the layout allows
+    int boxes_mode = 1;                    // mrt_debug_set_boxes: 0 = the boxes never reject (diagnostic), 1 / 2 = they do
     float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
     // hierarchy depth rule (build_hierarchy): levels are added while the top has more than top_target records; 0 = automatic
     // (256, or 128 for scenes whose walk tests boxes)

@@ -19,6 +19,8 @@ constexpr uint32_t kMaxLevels = 4;       // levels of bounding spheres above the
 constexpr float kBoundStretch = 1.0001f;
 constexpr double kBoundInflate = 1.015;
 constexpr uint32_t kMaxFrameBatch = 32;   // frames one render launch may cover (stream mode, mrt_render)
+constexpr uint32_t kQueueCap = 320;      // a work queue of the walk: < 64 left over + 4 x 64 pushed by one round
+constexpr uint32_t kStackReserve = 16;   // large scenes' work stack: entries beyond its capacity a one-item round may use (3 per level)
 constexpr uint32_t kMaxDirect = 4;       // very large spheres tested by every ray directly, outside the hierarchy
 
 // (cx, cy, cz, -(r*r)): the only per-sphere data the discriminant loop reads.  Derived on
@@ -68,12 +70,15 @@ struct KParams {
     const uint32_t* member_index;
     uint32_t levels, n_nodes, n_members, gen_cap;
     uint32_t level_base[kMaxLevels];
-    // boxes of the nodes of level k (1 <= k <= levels; level `levels` = the swept top) at boxes[box_base[k]], parallel to
-    // the level's records; box_top = box_base[levels].  use_boxes: the walk tests them (large scenes only); box_quad: the
-    // form of the slack.  Null / 0 for small scenes.
+    // Large scenes (more than 1,024 member slots): the axis-aligned boxes of the hierarchy's nodes, numbered TOP-DOWN over the
+    // complete 4-ary tree below the n_padded swept records: depth t occupies [o_t, o_t + n_padded 4^t), o_t = n_padded
+    // (4^t - 1) / 3, so the children of node g -- whatever its depth -- are 4 g + n_padded .. + 3 (never-hit boxes where the
+    // tree has no node).  box_cluster_first = o_(levels - 1): the nodes from there on are the clusters (node g = cluster
+    // g - box_cluster_first, members 4 m .. 4 m + 3 of level 0); box_cluster_parent_first = o_(levels - 2): the nodes from
+    // there on have clusters as children.  box_quad: the form of the slack (selects the kernel instantiation).  gen_cap is
+    // the capacity of the wave's work stack.  Null / 0 for small scenes.
     const BoxRec* boxes;
-    uint32_t box_base[kMaxLevels + 1];
-    uint32_t box_top, use_boxes, box_quad;
+    uint32_t box_cluster_first, box_cluster_parent_first, box_quad;
     // Spheres far larger than the rest (a ground sphere) are candidates for nearly every ray: up to kMaxDirect
     // of them stay out of the hierarchy and every ray evaluates their discriminant itself, from SGPRs.
     // They are the members direct_first .. direct_first + n_direct - 1 of level 0.
@@ -126,6 +131,10 @@ int launch_render(const KParams& p, bool pilot, uint32_t n_waves, void* stream, 
 int launch_finalize(const KParams& p, void* stream);
 int launch_debug_world_hit(const KParams& p, uint32_t n_waves, void* stream);
 int render_waves_per_cu(int* out);
+// host only: {LDS bytes of one render workgroup, workgroups per CU} for p's scene layout; the work-stack capacity (entries)
+// of a large scene's wave with `mask_chunks` chunks of candidate masks
+void render_lds_layout(const KParams& p, uint32_t out[2]);
+uint32_t large_scene_stack_cap(uint32_t mask_chunks);
 // tile_order.hip: order[] = tile ids sorted by cost[] descending (bucket sort; ties in any order).
 // scratch: 1024 u32.
 int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, uint32_t n_tiles, void* stream);

@@ -89,10 +89,10 @@ def check_kernel(name, lines):
                 if sregs(ops.split(",", 1)[1]) & dest:
                     errors.append(f"{name}: `{l}` (line {k}) reads {m.group(1)} while in flight")
             stack.extend(successors(k))
-    # render_kernel<COUNT, PILOT, CTR, SMALL, MFMA, DBG>: the matrix-core variant of the sweep (fifth argument
-    # true, mangled render_kernelILb?ELb?ELb?ELb?ELb1ELb?EEEv...) has no hand-issued scalar loads; every other one must have them
-    targs = re.search(r"render_kernelI((?:Lb[01]E)+)E", name)
-    flags = re.findall(r"Lb([01])E", targs.group(1)) if targs else []
+    # render_kernel<COUNT, PILOT, CTR, SC, MFMA, DBG>: the matrix-core variant of the sweep (fifth argument
+    # true, mangled render_kernelILb?ELb?ELb?ELi?ELb1ELb?EEEv...) has no hand-issued scalar loads; every other one must have them
+    targs = re.search(r"render_kernelI((?:L[bi][0-9]+E)+)E", name)
+    flags = re.findall(r"L[bi]([0-9]+)E", targs.group(1)) if targs else []
     mfma_variant = len(flags) >= 5 and flags[4] == "1"
     if loads == 0 and not mfma_variant:
         errors.append(f"{name}: no hand-issued s_load_dwordx16 found (sweep not recognised)")

@@ -25,7 +25,7 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 
     if os.environ.get("MRT_CLUSTER"):
         _lib.load().mrt_debug_set_cluster_factor(st._ctx, float(os.environ["MRT_CLUSTER"]))
     st.set_world(sp); st.set_camera(cam); st.set_rng_mode(mode)
-    st.render(max(2, int(os.environ.get('MRT_SLOTS', '2')))); st.sync()
+    st.render(int(os.environ.get('MRT_WARMUP', '8'))); st.sync()       # (a pixel-starved shard runs up to 8 frames at a time)
     c0 = st.read_counters()
     t0 = time.perf_counter(); st.render(K); st.sync(); dt = time.perf_counter() - t0
     c1 = st.read_counters()

@@ -15,11 +15,13 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     if os.environ.get('MRT_SCHED'):
         a_ = [int(x) for x in os.environ['MRT_SCHED'].split(',')]
         st.debug_set_schedule(a_[0], a_[1])
+    if os.environ.get("MRT_SLOTS"):
+        st.debug_set_frames_in_flight(int(os.environ["MRT_SLOTS"]))
     st.set_world(sp)
     if cam is not None: st.set_camera(cam)
     if os.environ.get("MRT_RNG"): st.set_rng_mode(int(os.environ["MRT_RNG"]))
     st.set_draw_counting(False)
-    for _ in range(2): st.redraw()
+    for _ in range(max(2, int(os.environ.get('MRT_SLOTS', '2')))): st.redraw()
     st.sync()
     c0 = st.read_counters()
     t0 = time.perf_counter()

@@ -169,3 +169,46 @@ def test_c5_counter_mode_at_4096_spp_whole_frame_and_eighth_shares(mrt):
         assert int(pc[lrow].sum()) == rc["world_hit_calls"]
         band = slice(lrow - lrow % 8, lrow - lrow % 8 + 8)
         assert np.array_equal(part[band].view(np.uint32), fb[y - y % 8:y - y % 8 + 8].view(np.uint32)), f"rank {rank}: band of row {y}"
+
+
+def test_c5_stream_mode_eighth_shares_with_eight_frames_in_flight(mrt):
+    """The launch shape of `bench.py --config c5 --gpus 8` in the reference's RNG semantics: a 1/8 share of C5 is pixel-starved
+    (259,200 pixels for 262,144 resident lanes, one sequential 4,096-sample chain each), so mrt_redraw runs up to eight such
+    frames at a time, each on an eighth of the waves (api.cpp redraw_frames).  For the ranks that own the fixture rows 10 / 500
+    / 900: frame 0 of the share against the oracle's rows (and the pixel costs against their world_hit_calls); then three
+    frames issued back to back -- in flight together -- against the same three frames rendered strictly one after the other:
+    scheduling must not change a bit."""
+    cfg = META["c5"]
+    sc, cam = _scene(mrt, cfg["scene"])
+    args = mrt.Args(cfg["width"], cfg["height"], cfg["spp"], cfg["depth"], 1.0)
+    world = 8
+    rows = [rc["row"] for rc in cfg["row_counters"][0]]
+    assert len({(y // 8) % world for y in rows}) == len(rows)            # three different ranks
+    for rc in cfg["row_counters"][0]:
+        y = rc["row"]
+        rank, lrow = (y // 8) % world, (y // 8) // world * 8 + y % 8
+        assert mrt.shard_global_row(lrow, rank, world) == y
+        with mrt.State(args, seed=cfg["seed"], shard=(rank, world)) as st:
+            st.set_world(sc)
+            st.set_camera(cam)
+            st.redraw()
+            st.sync()
+            part, pc = st.read_framebuffer(), st.debug_read_pixel_costs()
+            assert np.array_equal(part[lrow].view(np.uint32), ROWS[f"c5_f0_row{y}"].view(np.uint32)), f"rank {rank} of 8: global row {y}"
+            assert int(pc[lrow].sum()) == rc["world_hit_calls"]
+            if y != rows[0]:
+                continue                    # (the pipelined comparison once: 6 more share-frames)
+            st.reset()
+            for _ in range(3):
+                st.redraw()                 # no sync in between: the frames overlap on their own streams
+            st.sync()
+            piped = st.read_framebuffer()
+        with mrt.State(args, seed=cfg["seed"], shard=(rank, world)) as st:
+            st.debug_set_frames_in_flight(1)
+            st.set_world(sc)
+            st.set_camera(cam)
+            for _ in range(3):
+                st.redraw()
+                st.sync()
+            serial = st.read_framebuffer()
+        assert np.array_equal(piped.view(np.uint32), serial.view(np.uint32)), "frames in flight changed the accumulated image"

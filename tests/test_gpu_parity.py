@@ -152,16 +152,28 @@ def test_counter_mode_large_scene_and_shards(mrt, oracle):
 
 
 def test_every_render_kernel_instantiation_against_the_oracle(mrt, oracle):
-    """render_kernel<COUNT, PILOT, CTR, SMALL, MFMA> has 16 frame instantiations and 8 pilot ones (the pilot never counts);
-    the DBG ones (4) are what tests/test_gpu_superset.py drives.  Every one of them renders a frame here that must equal the
+    """render_kernel<COUNT, PILOT, CTR, SC, MFMA> has 24 frame instantiations and 12 pilot ones (the pilot never counts);
+    the DBG ones (6) are what tests/test_gpu_superset.py drives.  Every one of them renders a frame here that must equal the
     oracle's: {with, without the RNG draw counter} x {stream, counter RNG} x {small-scene layout: cover scene; large-scene
-    layout with boxes: 1,297 spheres} x {SGPR-fed VALU sweep, matrix-core sweep}, each with the schedule forced so that the
-    frame is preceded by a cost-estimating pilot launch (more tiles than persistent waves, 16 spp >= 8 x pilot spp) --
-    mrt_debug_last_launch reports which instantiations actually ran."""
+    layout with the quadratic form of the box slack: 1,297 spheres; with the linear form: the same plus 100 spheres up to 5,000
+    units away} x {SGPR-fed VALU sweep, matrix-core sweep}, each with the schedule forced so that the frame is preceded by a
+    cost-estimating pilot launch (more tiles than persistent waves, 16 spp >= 8 x pilot spp) -- mrt_debug_last_launch reports
+    which instantiations actually ran."""
+    from test_hierarchy_host import build_boxes
     w, h, spp, depth = 192, 136, 16, 12
     seen_main, seen_pilot = set(), set()
-    for small in (True, False):
+    far_rng = np.random.default_rng(9)
+    for layout in ("small", "large-quad", "large-linear"):
+        small = layout == "small"
         sc, cam = mrt.scene_cover(1, True) if small else mrt.scene_stress(5, 36)
+        if layout == "large-linear":
+            far = np.zeros(100, mrt.SPHERE_DTYPE)
+            far["center"] = (far_rng.uniform(-1.0, 1.0, (100, 3)) * [5000.0, 50.0, 5000.0]).astype(np.float32)
+            far["radius"] = far_rng.uniform(0.1, 0.2, 100).astype(np.float32)
+            far["material_ty"], far["albedo"] = 1, 0.5
+            sc = np.concatenate([sc, far])
+        if not small:
+            assert build_boxes(mrt, sc)["quad"] == (layout == "large-quad")
         for ctr in (0, 1):
             cnt = oracle.Counters()
             ref = oracle_render(oracle, sc, cam, w, h, spp, depth, seed=12, counters=cnt, rng_mode=ctr)
@@ -170,7 +182,6 @@ def test_every_render_kernel_instantiation_against_the_oracle(mrt, oracle):
                     with mrt.State(mrt.Args(w, h, spp, depth), seed=12) as st:
                         st.debug_set_schedule(2, 1)                 # 1 wave per CU: fewer waves than the 408 tiles
                         st.debug_set_sweep(sweep)
-                        st.debug_set_boxes(True)                    # (by default only scenes beyond 4,096 member slots walk boxes)
                         st.set_world(sc)
                         st.set_camera(cam)
                         st.set_rng_mode(ctr)
@@ -178,12 +189,13 @@ def test_every_render_kernel_instantiation_against_the_oracle(mrt, oracle):
                         st.redraw()
                         got, c = st.read_framebuffer(), st.read_counters()
                         main, pilot = st.debug_last_launch()
-                    what = f"small={small} ctr={ctr} sweep={sweep} count={count}"
+                    what = f"{layout} ctr={ctr} sweep={sweep} count={count}"
                     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), what + ": " + mismatch_report(got, ref)
                     assert c["samples"] == cnt.samples and c["world_hit_calls"] == cnt.world_hit_calls, what
                     assert c["rng_draws"] == (cnt.rng_draws if count else 0), what
-                    assert main == (1 if count else 0) | (4 if ctr else 0) | (8 if small else 0) | (16 if sweep == 2 else 0), (what, main)
-                    assert pilot == 2 | (4 if ctr else 0) | (8 if small else 0) | (16 if sweep == 2 else 0), (what, pilot)
+                    bits = (4 if ctr else 0) | (8 if small else 0) | (16 if sweep == 2 else 0) | (32 if layout == "large-quad" else 0)
+                    assert main == (1 if count else 0) | bits, (what, main)
+                    assert pilot == 2 | bits, (what, pilot)
                     seen_main.add(main)
                     seen_pilot.add(pilot)
-    assert len(seen_main) == 16 and len(seen_pilot) == 8
+    assert len(seen_main) == 24 and len(seen_pilot) == 12

@@ -101,7 +101,7 @@ def test_hierarchy_depth_does_not_change_pixels(mrt, oracle, n):
     for max_levels, top_target, boxes in [(1, 64, True), (2, 64, True), (3, 8, True), (4, 1, True), (4, 64, True), (3, 8, False), (4, 64, False)]:
         with mrt.State(mrt.Args(56, 32, 3, 9, 1.0), seed=77) as st:
             st.debug_set_hierarchy(max_levels, top_target)
-            st.debug_set_boxes(boxes)         # the walk's box tests (default) or bounding spheres only: the same image
+            st.debug_set_boxes(boxes)         # the walk's box tests (default) or boxes opened wide (they never reject): the same image
             st.set_world(sc)
             st.set_camera(cam)
             st.render(1)

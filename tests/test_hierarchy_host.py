@@ -257,3 +257,26 @@ def test_every_box_encloses_the_spheres_under_it_and_its_slack_covers_the_discri
                         need = 1.4143 * min(14 * eps * oc * oc / (2 * r_min * 0.99999), np.sqrt(14 * eps / 0.99999) * oc) + 4 * eps * np.sqrt(3) * dist
                         have = kc * dist * dist + kpad if b["quad"] else kc * dist + kpad       # (|p|_1 >= |p|_2)
                         assert have >= need, (name, k, j, dist, have, need, b["quad"])
+
+
+def test_lds_footprint_keeps_the_residency_the_kernels_are_built_for(mrt):
+    """The persistent grid is sized from the workgroup's LDS footprint (kernels.hip, render_lds_layout): 5 workgroups per CU for
+    the headline scene (C3: 5 waves per SIMD, 96 VGPRs), 4 for large scenes (C5: the wave's work stack is sized to fill exactly a
+    quarter of the CU's 160 KB).  A layout change that drops either fails here instead of costing throughput unnoticed."""
+    L = _lib.load()
+    out = (C.c_uint32 * 3)()
+
+    def layout(sc, max_levels=4, top_target=0):
+        h = build(mrt, sc, max_levels, top_target)
+        assert L.mrt_debug_lds_layout(h["n_members"], len(h["nodes"]), h["levels"], len(h["top"]), out) == 0
+        return h, out[0], out[1], out[2]
+
+    h, lds, groups, cap = layout(mrt.scene_cover(1, True)[0])
+    assert h["levels"] == 1 and groups == 5 and lds * 5 <= 160 * 1024, (lds, groups)
+    h, lds, groups, cap = layout(mrt.scene_stress(1, 100)[0])
+    assert h["levels"] == 4 and len(h["top"]) == 64
+    assert groups == 4 and 4 * lds == 160 * 1024 and cap >= 768, (lds, groups, cap)           # every byte used: the stack
+    # any large scene, whatever its hierarchy: 4 groups per CU and a work stack that holds a round's pushes several times over
+    for n_side, levels, target in [(36, 4, 0), (36, 1, 64), (50, 2, 8), (70, 4, 16), (100, 3, 256)]:
+        h, lds, groups, cap = layout(mrt.scene_stress(2, n_side)[0], levels, target)
+        assert groups == 4 and lds * 4 <= 160 * 1024 and cap >= 400, (n_side, levels, target, lds, groups, cap)
