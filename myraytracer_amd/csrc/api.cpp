@@ -117,6 +117,7 @@ int alloc_frame_buffers(mrt_ctx* c) {
         S.pix_acc_layers = 1;
     }
     c->frame_slots = 2;
+    c->width_div = 0;
     c->inputs_dirty = true;
     // as many persistent single-wave workgroups as the chip holds
     {
@@ -616,6 +617,7 @@ hipError_t create_slot_streams(mrt_ctx::FrameSlot& S) {
     if (!S.stream) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
     if (e == hipSuccess && !S.render_done) e = hipEventCreateWithFlags(&S.render_done, hipEventDisableTiming);
     if (e == hipSuccess && !S.finalize_done) e = hipEventCreateWithFlags(&S.finalize_done, hipEventDisableTiming);
+    if (e == hipSuccess && !S.stats_ready) e = hipEventCreateWithFlags(&S.stats_ready, hipEventDisableTiming);
     return e;
 }
 
@@ -816,6 +818,7 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
         if (hipEventCreate(&c->ev_start[i]) != hipSuccess || hipEventCreate(&c->ev_stop[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
     if (hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) { c->err = "counter allocation failed"; return bail(MRT_ERR_HIP); }
+    if (hipHostMalloc((void**)&c->h_stats, 2 * mrt_ctx::kMaxFrameSlots * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { c->err = "pinned allocation failed"; return bail(MRT_ERR_HIP); }
     int st = alloc_frame_buffers(c);
     if (st != MRT_OK) return bail(st);
     *out = c;
@@ -830,11 +833,13 @@ void mrt_destroy(mrt_ctx* c) {
     for (auto& S : c->slot) {
         if (S.render_done) (void)hipEventDestroy(S.render_done);
         if (S.finalize_done) (void)hipEventDestroy(S.finalize_done);
+        if (S.stats_ready) (void)hipEventDestroy(S.stats_ready);
         if (S.stream) (void)hipStreamDestroy(S.stream);
     }
     if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
     free_world(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->d_wave_log) (void)hipFree(c->d_wave_log);
     if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->d_gather_stage) (void)hipFree(c->d_gather_stage);
@@ -991,6 +996,7 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
     for (auto& S : c->slot) S.cost_valid = false;
+    c->width_div = 0;                   // (the launch-width controller starts over with the new workload)
     c->inputs_dirty = true;
     c->world = *w;
     c->n_spheres = (uint32_t)n;
@@ -1033,6 +1039,7 @@ int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
             return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_camera: |lookfrom| or the lens radius exceeds 1e7");
     c->cam_raw = raw;
     for (auto& S : c->slot) S.cost_valid = false;
+    c->width_div = 0;                   // (the launch-width controller starts over with the new workload)
     return MRT_OK;
 }
 
@@ -1160,25 +1167,90 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     p.wave_log = c->d_wave_log;
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
     p.pilot_spp = c->pilot_spp;
-    // how many frames may be in flight from here on (mrt_ctx::kMaxFrameSlots); a change waits for the frames under way
-    bool starved = false;
+    // Launch width and frames in flight (mrt_ctx::width_div): a change waits for the frames under way.
+    const bool adaptive = batch == 1 && c->waves_per_cu_override == 0 && c->frame_slots_override == 0 &&
+                          c->locals.samples_per_frame >= 4u && c->n_tiles != 0;
     {
-        // A pixel-starved launch of long chains (fewer than two pixels per lane the chip holds, one sequential chain of >= 64
-        // samples each: an 8-GPU share of C5) lasts as long as its heaviest pixel while most of its waves are done far earlier,
-        // and a wave's iteration takes the same time at 1 to 4 waves per SIMD.  So such frames run EIGHT at a time on an eighth
-        // of the waves each: the lanes stay packed (8 pixels per lane in sequence) and the chip full.  Measured on C5's 1/8
-        // share, one mrt_redraw per frame: 885 Msamples/s at 0.41 lane utilisation (2 frames in flight on all waves) ->
-        // 2,367 at 0.92 (DESIGN_HISTORY.md, round 4).
-        starved = !counter && batch == 1 && c->locals.samples_per_frame >= 64u && c->waves_per_cu_override == 0 &&
-                  (uint64_t)c->n_tiles < 2ull * c->n_waves && c->n_tiles > c->n_waves / mrt_ctx::kMaxFrameSlots;
-        const uint32_t want = c->frame_slots_override > 0 ? (uint32_t)c->frame_slots_override : starved ? mrt_ctx::kMaxFrameSlots : 2u;
+        uint32_t want = c->frame_slots_override > 0 ? (uint32_t)c->frame_slots_override : 2u;
+        if (adaptive) {
+            if (c->width_div == 0) {
+                // what is known up front.  A pixel-starved launch of long chains (fewer than two pixels per lane the chip holds,
+                // one sequential chain of >= 64 samples each: an 8-GPU share of C5) lasts as long as its heaviest pixel while
+                // most of its waves are done far earlier, and a wave's iteration takes the same time at 1 to 4 waves per SIMD:
+                // eight frames at a time on an eighth of the waves each (C5's 1/8 share, one mrt_redraw per frame: 885
+                // Msamples/s at 0.41 lane utilisation with 2 frames in flight on all waves -> 2,490 at 0.88).  Large scenes:
+                // a half (their pixels' chains differ 10 x; every large scene measured gains or stays within 1 %).
+                const bool starved = !counter && c->locals.samples_per_frame >= 64u && (uint64_t)c->n_tiles < 2ull * c->n_waves &&
+                                     c->n_tiles > c->n_waves / mrt_ctx::kMaxFrameSlots;
+                c->width_div = starved ? mrt_ctx::kMaxFrameSlots : (!counter && c->n_members > 1024u && c->n_tiles >= 4u * c->n_waves) ? 2u : 1u;
+                c->width_valid_from = c->frame_seq + std::max(2u, c->width_div);
+                c->stat_base.valid = c->stat_last.valid = false;
+                c->width_prev = 0; c->width_settled = false; c->width_timing = false;
+            }
+            // The host may not run further ahead than the frames in flight: before a slot is used again, its previous frame's
+            // render kernel has completed (a swap-chain's back-pressure; the GPU still holds a full set of frames, queued or
+            // running).  It bounds the queued work and is what lets the samples below arrive while they can still matter -- a
+            // caller that issues its redraws in one burst would otherwise see none of them before its last call.
+            {
+                mrt_ctx::FrameSlot& Own = c->slot[c->frame_seq % c->frame_slots];
+                if (Own.stats_pending) HIP_TRY(c, hipEventSynchronize(Own.stats_ready));
+            }
+            // lane-utilisation samples that have landed (an event that is not ready yet is looked at next time)
+            for (uint32_t i = 0; i < c->frame_slots; i++) {
+                mrt_ctx::FrameSlot& T = c->slot[i];
+                if (!T.stats_pending || hipEventQuery(T.stats_ready) != hipSuccess) continue;
+                T.stats_pending = false;
+                if (T.stats_seq < c->width_valid_from) continue;
+                mrt_ctx::LaneStat st{T.stats_seq, c->h_stats[2 * i], c->h_stats[2 * i + 1], true};
+                if (!c->stat_base.valid || st.seq < c->stat_base.seq) c->stat_base = st;
+                if (!c->stat_last.valid || st.seq > c->stat_last.seq) c->stat_last = st;
+            }
+            (void)hipGetLastError();        // (hipEventQuery's hipErrorNotReady is not an error)
+            // A measurement window: from the first frame launched at the current width with the pipeline full, over
+            // 2 x (frames in flight) + 2 frames -- their lane utilisation (the samples above) and, the calls being paced by
+            // the completions (the back-pressure above), their rate on the host's clock.
+            const uint32_t in_flight = std::max(2u, c->width_div);
+            const auto now = std::chrono::steady_clock::now();
+            if (!c->width_settled && !c->width_timing && c->frame_seq >= c->width_valid_from) {
+                c->width_timing = true;
+                c->width_t0_seq = c->frame_seq;
+                c->width_t0 = now;
+            }
+            if (c->width_timing && c->frame_seq >= c->width_t0_seq + 2u * in_flight + 2u && c->stat_base.valid && c->stat_last.valid &&
+                c->stat_last.seq > c->stat_base.seq && c->stat_last.slots > c->stat_base.slots && c->stat_last.hits >= c->stat_base.hits) {
+                const double util = (double)(c->stat_last.hits - c->stat_base.hits) / (double)(c->stat_last.slots - c->stat_base.slots);
+                const double rate = (double)(c->frame_seq - c->width_t0_seq) / std::max(1e-9, std::chrono::duration<double>(now - c->width_t0).count());
+                uint32_t next_div = c->width_div;
+                if (c->width_prev != 0) {                    // a trial ends: keep the narrower width only if it pays
+                    if (rate < 1.03 * c->width_prev_rate) { next_div = c->width_prev; c->width_settled = true; }
+                    c->width_prev = 0;
+                }
+                if (!c->width_settled) {
+                    // (narrower only while a launch's waves still get at least two tiles each)
+                    const uint32_t cand = c->width_div == 1u ? 4u : c->width_div * 2u;
+                    if (util < 0.95 && cand <= mrt_ctx::kMaxFrameSlots && (uint64_t)c->n_tiles * cand >= 2ull * c->n_waves && c->n_waves >= cand) {
+                        c->width_prev = c->width_div;
+                        c->width_prev_rate = rate;
+                        next_div = cand;
+                    } else {
+                        c->width_settled = true;
+                    }
+                }
+                c->width_div = next_div;
+                c->width_timing = false;
+                c->width_valid_from = c->frame_seq + std::max(2u, next_div);       // (the frames at the old width drain first)
+                c->stat_base.valid = c->stat_last.valid = false;
+            }
+            want = std::max(2u, c->width_div);
+        }
         if (want != c->frame_slots) {
             HIP_TRY(c, sync_all(c));
             c->frame_slots = want;
-            // the further slots' colour sums now, in one go: allocated on first use each would wait for the frames in flight
+            // the further slots' streams and colour sums now, in one go: allocated on first use each would wait for the frames in flight
             for (uint32_t i = 0; i < want; i++) {
                 mrt_ctx::FrameSlot& T = c->slot[i];
                 HIP_TRY(c, create_slot_streams(T));
+                T.stats_pending = false;
                 if (T.pix_acc_layers != 0) continue;
                 const size_t nt = local_texels(c) ? local_texels(c) : 1;
                 HIP_TRY(c, hipMalloc(&T.d_pix_acc, nt * 16));
@@ -1248,7 +1320,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     // iteration is shorter (1080p, 1 spp: 20 waves per CU 0.74 ms, 8 waves 0.42 ms; DESIGN_HISTORY.md round 3).
     uint32_t launch_waves = c->n_waves;
     if (chain_spp < 4u && c->waves_per_cu_override == 0) launch_waves = std::min(launch_waves, c->cus * 8u);
-    if (starved) launch_waves = std::max(c->n_waves / c->frame_slots, 1u);         // (above: frames in flight)
+    if (adaptive) launch_waves = std::max(c->n_waves / std::max(c->width_div, 1u), 1u);         // (above: launch width)
     if (c->lpt_enabled && c->n_tiles > launch_waves && chain_spp >= 4u) {
         if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
             int pe = mrt::launch_render(p, true, launch_waves, S.stream, &c->last_launch[1]);
@@ -1268,6 +1340,13 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], S.stream));
     HIP_TRY(c, hipEventRecord(S.render_done, S.stream));
+    if (adaptive) {         // the launch-width controller's sample: cumulative world_hit calls and lane slots after this kernel
+        HIP_TRY(c, hipMemcpyAsync(c->h_stats + 2 * c->last_slot, c->d_counters + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_stats + 2 * c->last_slot + 1, c->d_counters + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
+        HIP_TRY(c, hipEventRecord(S.stats_ready, S.stream));
+        S.stats_seq = c->frame_seq;
+        S.stats_pending = true;
+    }
     c->timed_frames++;
     // caller's stream: blend into the accumulated framebuffer (shader.wgsl:383-385) once the render is done -- frame by frame
     HIP_TRY(c, hipStreamWaitEvent(c->stream, S.render_done, 0));
@@ -1307,7 +1386,10 @@ int mrt_render(mrt_ctx* c, uint32_t frames) {
         uint32_t batch = 1;
         if (c->batch_frames && frames >= 2 && c->locals.rng_mode == MRT_RNG_PIXEL_STREAM && !c->shuffle_overridden && c->n_tiles != 0) {
             // too few pixels to fill the GPU (fewer than two per lane): about six pixel chains per lane (they differ 10 x in length)
-            uint32_t want = c->n_tiles < 2u * c->n_waves ? (6u * c->n_waves + c->n_tiles - 1u) / c->n_tiles : 1u;
+            // -- for SHORT chains only: from 64 samples per pixel on, frames launched one by one run eight at a time on an eighth
+            // of the waves each (redraw_frames), which packs the lanes better than the layers of a batch do (C5's 1/8 share:
+            // 2,380 Msamples/s at 0.68 lane utilisation in batches of 7, 2,660 at 0.92 frame by frame)
+            uint32_t want = (c->n_tiles < 2u * c->n_waves && c->locals.samples_per_frame < 64u) ? (6u * c->n_waves + c->n_tiles - 1u) / c->n_tiles : 1u;
             // too short a frame (1 spp interactive accumulation: 0.2 ms of work behind six launches): about 128 M samples per launch
             const uint64_t per_frame = (uint64_t)c->n_tiles * 64u * std::max(c->locals.samples_per_frame, 1u);
             want = std::max<uint64_t>(want, ((128ull << 20) + per_frame - 1) / per_frame);
@@ -1323,7 +1405,7 @@ int mrt_render(mrt_ctx* c, uint32_t frames) {
         // more than the acquisitions cost from 8 samples up -- measured, DESIGN.md: 1 spp 5,470 -> 10,360 Msamples/s, 8 spp
         // 11,260 -> 11,050, C2's 64 spp 11,640 -> 10,650.)
         const bool starved = c->n_tiles < 2u * c->n_waves;
-        const bool in_lane = !starved && c->locals.samples_per_frame < 4u;
+        const bool in_lane = !starved && c->locals.samples_per_frame < 4u;      // (a batch of 1 is a plain redraw, whatever its form)
         int st = redraw_frames(c, batch, c->batch_form == 0 ? in_lane : c->batch_form == 1);
         if (st != MRT_OK) return st;
         frames -= batch;
@@ -1631,6 +1713,7 @@ int mrt_set_rng_shuffle(mrt_ctx* c, const uint32_t s[4]) {
 int mrt_set_rng_mode(mrt_ctx* c, uint32_t mode) {
     if (!c || mode > MRT_RNG_COUNTER) return MRT_ERR_INVALID_ARG;
     c->locals.rng_mode = mode;
+    c->width_div = 0;
     return MRT_OK;
 }
 
@@ -1643,6 +1726,7 @@ int mrt_set_draw_counting(mrt_ctx* c, int enabled) {
 int mrt_set_samples_per_frame(mrt_ctx* c, uint32_t spp) {
     if (!c) return MRT_ERR_INVALID_ARG;
     c->locals.samples_per_frame = spp;
+    c->width_div = 0;
     return MRT_OK;
 }
 

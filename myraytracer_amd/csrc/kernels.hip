@@ -15,8 +15,9 @@
 //     loads into SGPRs (10 fp32 VALU ops + 1 v_alignbit); either way the signs land in per-lane bitmasks
 //     kept in LDS -- and (2) a COOPERATIVE walk: the candidates of all 64 rays become work items (owner lane, node)
 //     in small LDS queues and every round 64 lanes take 64 items, whoever owns them: node rounds
-//     evaluate the reference's discriminant for the 4 members of a cluster (or the conservative test
-//     for the 4 children of an inner node), root rounds its sqrt / divide / range tests
+//     evaluate the reference's discriminant for the 4 members of a cluster (large scenes, above it: the line
+//     against the axis-aligned boxes of the 4 children of an inner node, all inner levels on ONE work stack),
+//     root rounds its sqrt / divide / range tests
 //     (shader.wgsl:286-296) for members with disc >= 0 and merge them into the owner's slot by a
 //     64-bit LDS minimum over (t, sphere index), which is what the reference's index-order scan yields;
 //   * persistent waves pull 8x8 tiles from one global heaviest-first queue and a lane that
@@ -313,11 +314,12 @@ constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 
 
 // The cooperative walk: candidates found by the sweep become wave-wide work items
 // (owner lane, node) in small LDS queues; every round 64 lanes take 64 items, whoever owns them.
-// The bounding spheres form a 4-ary hierarchy of P.levels levels above the member spheres (level 0);
-// the sweep tests the top level, the walk descends:
-//   queue P.levels : (owner, top node)   written by the owners from their sweep masks
-//   queue k        : (owner, level-k node) whose bound the owner's ray may touch, 1 <= k < P.levels
-//   queue 0        : (owner, member)     members whose discriminant is >= 0, waiting for the root tests
+// The bounds form a 4-ary hierarchy of P.levels levels above the member spheres (level 0);
+// the sweep tests the top level's bounding spheres, the walk descends.  Small scenes (one level):
+//   queue 1 : (owner, cluster)  written by the owners from their sweep masks
+//   queue 0 : (owner, member)   members whose discriminant is >= 0, waiting for the root tests
+// Large scenes: raw candidates -> (box filter) -> one stack of inner nodes of every level -> clusters -> members
+// (render_kernel, "Large scenes").
 // (kQueueCap, mrt_internal.h: < 64 left over + 4 x 64 pushed by one round; the small scenes' top queue: P.gen_cap)
 // Large scenes keep ONE work stack of P.gen_cap entries for all inner levels (render_kernel) + this reserve: a round is sized
 // so that its pushes fit (<= 4 per item), down to one item per round, which may exceed the capacity by 3 entries per level

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <string>
 
 #include "mrt_internal.h"
@@ -85,7 +86,30 @@ struct mrt_ctx {
         // The tile queue's counter is left at zero by every finalize pass of the slot.  If anything between a render launch
         // and its last finalize launch fails, it is not: the next launch on this slot resets it itself.
         bool queue_dirty = false;
+        // launch-width controller: the context's cumulative {world_hit calls, lane slots} copied to pinned host memory right
+        // after this slot's render kernel (h_stats[2 slot ..]), the event that says the copy has landed, the frame it was
+        hipEvent_t stats_ready = nullptr;
+        uint64_t stats_seq = 0;
+        bool stats_pending = false;
     } slot[kMaxFrameSlots];
+    // Launch width (redraw_frames): a frame is launched on n_waves / width_div persistent waves and max(2, width_div) frames are
+    // in flight, so that the chip stays full.  Narrow launches pack the lanes better (more pixels per lane in sequence: the
+    // launch's tail, in which lanes idle until their wave's longest pixel ends, is the same length but a smaller share) at the
+    // price of a longer frame latency -- and they do not always pay (C3 / C4, 0.98 / 0.99 lane utilisation at full width, lose
+    // 1-4 % at a half; C2 loses 4 % at a half and gains 18 % at a quarter).  So: width_div starts from what is known up front
+    // (8 for a pixel-starved shard of long chains, 2 for large scenes, else 1); while the measured lane utilisation at the
+    // current width is below 0.95 a narrower width is TRIED (x 4 from full width, then x 2) and kept only if the measured
+    // frame rate rises by 3 %, else the previous width returns and stays.  Scheduling only: the images do not change.
+    uint32_t width_div = 0;                         // 0 = not chosen yet for the current workload
+    uint32_t width_prev = 0;                        // the width a running trial would return to (0 = no trial)
+    bool width_settled = false;                     // no further trials for this workload
+    double width_prev_rate = 0.0;                   // frames / s measured at width_prev
+    uint64_t width_valid_from = 0;                  // frame_seq from which samples and timings belong to the current width
+    bool width_timing = false;                      // a measurement window is open: since frame width_t0_seq, at width_t0
+    uint64_t width_t0_seq = 0;
+    std::chrono::steady_clock::time_point width_t0;
+    struct LaneStat { uint64_t seq = 0, hits = 0, slots = 0; bool valid = false; } stat_base, stat_last;
+    unsigned long long* h_stats = nullptr;          // pinned, 2 x kMaxFrameSlots
     hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
     bool inputs_dirty = true;
     uint64_t frame_seq = 0;

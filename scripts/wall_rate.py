@@ -21,7 +21,7 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     if cam is not None: st.set_camera(cam)
     if os.environ.get("MRT_RNG"): st.set_rng_mode(int(os.environ["MRT_RNG"]))
     st.set_draw_counting(False)
-    for _ in range(max(2, int(os.environ.get('MRT_SLOTS', '2')))): st.redraw()
+    for _ in range(int(os.environ.get('MRT_WARMUP', max(2, int(os.environ.get('MRT_SLOTS', '2')))))): st.redraw()      # (the launch-width controller settles within ~3 x the frames in flight)
     st.sync()
     c0 = st.read_counters()
     t0 = time.perf_counter()
