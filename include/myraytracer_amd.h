@@ -194,7 +194,9 @@ int mrt_read_seeds(mrt_ctx* ctx, uint32_t* out, size_t cap_u32);    /* this shar
 /* State::redraw (lib.rs:241-307) minus the present pass: one raytrace pass of
  * samples_per_frame spp into framebuffers.target blended with .secondary, swap,
  * sample_count += 1, framebuffer_weight = min(max_w, n/(n+1)), new rng_shuffle, Locals
- * update.  Asynchronous on the ctx's stream. */
+ * update.  Asynchronous on the ctx's stream, like a swap chain: consecutive frames overlap on the GPU (2 in flight; up to 8 for a
+ * shard with too few pixels to fill the chip), and the call returns at once unless that many frames are already queued -- then
+ * it waits for the oldest one's render kernel.  The next call's blend is ordered behind this one's on the ctx's stream. */
 int mrt_redraw(mrt_ctx* ctx);
 /* `frames` x mrt_redraw: the same images.  Frames are independent until their blend, so when the (shard of the) image has
  * fewer than about two pixels per GPU lane -- a pixel is one sequential chain of samples, lib.rs:299-306's remedy for that is

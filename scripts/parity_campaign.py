@@ -58,7 +58,7 @@ def main():
         if mode and rng.random() < 0.4:
             spp, w, h = int(rng.choice([64, 65, 130, 200])), min(w, 24), min(h, 16)
         seed = int(rng.integers(0, 2 ** 62))
-        frames = int(rng.choice([1, 1, 2, 5])) if spp <= 5 else 1          # several frames go through mrt_render's batches
+        frames = int(rng.choice([1, 1, 2, 5, 9])) if spp <= 5 else 1       # several frames go through mrt_render's batches, or the frame slots
         hier = (int(rng.integers(1, 5)), int(rng.choice([1, 4, 16, 64, 256])))
         lim = max(float(np.abs(sc["center"]).max()), float(np.abs(sc["radius"]).max()))
         if lim > 5e6:            # the ABI rejects |v| > 1e7
@@ -69,8 +69,9 @@ def main():
         with M.State(M.Args(w, h, spp, depth, 1.0), seed=seed) as st:
             st.debug_set_hierarchy(*hier)
             st.debug_set_sweep(int(rng.integers(0, 3)))      # automatic / VALU / matrix-core sweep
-            st.debug_set_boxes([True, True, True, False, 1][int(rng.integers(0, 5))])     # round 3: the walk's box tests: forced on, off, or automatic (beyond 4,096 member slots)
-            st.debug_set_frame_batching(int(rng.choice([1, 1, 2, 3])))     # automatic / frames in the lane / frames as queue layers
+            st.debug_set_boxes([True, True, True, False, 1][int(rng.integers(0, 5))])     # large scenes: real boxes, or boxes opened wide (they never reject)
+            st.debug_set_frame_batching(int(rng.choice([0, 1, 1, 2, 3])))  # frame by frame / automatic / frames in the lane / frames as queue layers
+            st.debug_set_frames_in_flight(int(rng.choice([0, 0, 1, 3, 8])))   # round 4: automatic / that many frames in flight
             count = bool(rng.random() < 0.7)
             st.set_draw_counting(count)
             st.set_world(sc)

@@ -1,0 +1,31 @@
+"""One value per quantity: every measured figure DESIGN.md / README.md quote carries a marker (`value<!--TOKEN-->`) and must
+equal, to the digits quoted, the value in the ONE file under profiles/ it comes from (scripts/docs_numbers.py).  Round 3 had
+three values for C3's VALU issue fraction in one commit (0.585 / 0.604 / 0.615): a refreshed profile now fails this test until
+the prose is regenerated (`python scripts/docs_numbers.py`)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def test_quoted_figures_equal_the_profiles():
+    from docs_numbers import check
+    bad, seen = check()
+    assert not bad, "\n".join(bad)
+    # the headline, the issue fractions, the other configs and the shard rates are all quoted through markers
+    for tok in ("C3_VALUE", "C3_ISSUE", "C3_VALU", "C5_ISSUE", "C5_VALUE", "C1_VALUE", "C2_VALUE", "C4_VALUE", "SHARD8_VALUE", "SHARD8_UTIL"):
+        assert tok in seen, f"{tok} is not quoted (or lost its marker)"
+
+
+def test_bench_and_profiles_describe_the_same_sources():
+    """The committed headline line, the PMC summaries bench.py copies its valu_issue from, and the library that produced the
+    line name one source hash."""
+    import json
+    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")))
+    assert b["lib_build_id"] == b["source_sha16"] and b["lib_matches_sources"] is True
+    for name in ("r04_c3_pmc.json", "r04_c5_pmc.json"):
+        assert json.load(open(os.path.join(ROOT, "profiles", name)))["source_sha16"] == b["source_sha16"], name
+    for name in ("r04_bench_c1_n1.json", "r04_bench_c2_n1.json", "r04_bench_c4_n1.json", "r04_bench_c5_n1.json"):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d["source_sha16"] == b["source_sha16"] and d["cpu_baseline"]["value"] > 0, name
