@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+SCLK_HZ = 2.4e9            # shader clock under this load (rocm-smi while the bench runs: 2,393 MHz)
 HANG_EXIT_CODE = 75       # a watchdog ended a hung N > 1 leg: the JSON line is complete and records the hang
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x Hz: fp32 VALU lane-ops/s
@@ -514,6 +515,11 @@ def main():
             # the bound that binds: VALU issue slots.  frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x cycles), per serialised launch
             # under rocprofv3 --pmc (committed profile of this command); ceiling = what a pure sweep / a brute-force frame reach
             "valu_issue": ({"frac": pmc.get("issue_frac"), "peak": 1.0, "measured_ceiling": [0.865, 0.886],
+                            # the same instruction count (deterministic for the workload) over THIS run's wall time per step: the
+                            # chip-wide figure when launches overlap or run narrower than the chip (frac is per serialised launch)
+                            "frac_over_wall_time": (pmc["valu_insts_per_launch"] * 2.0 / (1024.0 * kernel_s * SCLK_HZ)
+                                                    if pmc.get("valu_insts_per_launch") else None),
+                            "sclk_hz_assumed": SCLK_HZ,
                             "ceiling_source": "profiles/r01_ubench_pmc.txt (sweep microbenchmark; brute-force kernel over a frame)",
                             "thread_utilisation": pmc.get("thread_utilisation"),
                             "valu_insts_per_wave_bounce": pmc.get("valu_insts_per_wave_bounce"),

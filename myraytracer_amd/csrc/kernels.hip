@@ -318,8 +318,8 @@ constexpr uint32_t kBlockChunks = 16;     // 16 chunks x 16 clusters x 4 = 1024 
 // the sweep tests the top level's bounding spheres, the walk descends.  Small scenes (one level):
 //   queue 1 : (owner, cluster)  written by the owners from their sweep masks
 //   queue 0 : (owner, member)   members whose discriminant is >= 0, waiting for the root tests
-// Large scenes: raw candidates -> (box filter) -> one stack of inner nodes of every level -> clusters -> members
-// (render_kernel, "Large scenes").
+// Large scenes: every owner filters its candidates against their boxes in the lane -> one stack of inner nodes of every
+// level -> clusters -> members (render_kernel, "Large scenes").
 // (kQueueCap, mrt_internal.h: < 64 left over + 4 x 64 pushed by one round; the small scenes' top queue: P.gen_cap)
 // Large scenes keep ONE work stack of P.gen_cap entries for all inner levels (render_kernel) + this reserve: a round is sized
 // so that its pushes fit (<= 4 per item), down to one item per round, which may exceed the capacity by 3 entries per level
@@ -337,7 +337,7 @@ __host__ __device__ constexpr uint32_t lds_off_rays() { return 0u; }            
 __host__ __device__ constexpr uint32_t lds_off_ring() { return 2048u; }                // kRingCap x u32
 __host__ __device__ constexpr uint32_t lds_off_queues() { return 2048u + 512u; }
 __host__ __device__ constexpr uint32_t lds_queue_bytes(bool small, uint32_t levels, uint32_t gen_cap) {
-    return small ? (levels * kQueueCap + gen_cap) * 2u : (gen_cap + kStackReserve + 3u * kQueueCap) * 4u;     // large: raw, cluster, root queues + the inner levels' stack
+    return small ? (levels * kQueueCap + gen_cap) * 2u : (gen_cap + kStackReserve + 2u * kQueueCap) * 4u;     // large: cluster, root queues + the inner levels' stack
 }
 __host__ __device__ constexpr uint32_t lds_off_masks(bool small, uint32_t levels, uint32_t gen_cap) { return lds_off_queues() + lds_queue_bytes(small, levels, gen_cap); }
 __host__ __device__ constexpr uint32_t lds_wave_bytes(bool small, uint32_t levels, uint32_t gen_cap, uint32_t mask_chunks) {
@@ -818,66 +818,76 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         MRT_STAMP(2);
                     }
                 } else {
-                    // Large scenes.  Four queues, deepest first:
-                    //   raw      (owner, top record j) from the owners' masks: does the owner's line touch the record's BOX (the
-                    //            sweep tested its bounding sphere)?  Filter rounds, two items per lane (a filter round is
-                    //            mostly its chain of dependent reads item -> ray -> box, which two independent chains share).
+                    // Large scenes.  Every owner first FILTERS its own candidates -- does its line touch the record's BOX (the
+                    // sweep tested its bounding sphere)? -- in the lane: one record of its masks per trip, its ray in registers,
+                    // the record's box from L1, one box ahead.  (Round 3 wrote the raw candidates to a queue and read them back
+                    // in filter rounds: two LDS round trips and a round's fixed costs per candidate more; C5 +7 %.)  The
+                    // survivors feed three queues, deepest first:
                     //   inner    ONE stack for every level below the top: (owner, node g), g numbered top-down over the complete
                     //            4-ary tree (children of g = 4 g + P.n_padded .. + 3, whatever the level): test the 4 children's
-                    //            boxes.  A round takes the last 64 items whatever their levels -- the code is the same -- so that
-                    //            the three inner levels of C5 end a world_hit with ONE partial round instead of three.
+                    //            boxes.  A round takes the last 64 items whatever their levels -- the code is the same.
                     //   cluster  (owner, cluster-level node g): the reference's discriminant for the cluster's 4 members
                     //            (level 0, members 4 m .. 4 m + 3, m = g - P.box_cluster_first)
                     //   root     (owner, member): the root tests
-                    // A full round at the deepest queue that has one; else unpack more candidates; else a partial round at the
+                    // A full round at the deepest queue that has one; else filter more candidates; else a partial round at the
                     // HIGHEST queue that holds anything (what it pushes may still fill the queues below).
-                    constexpr uint32_t kPer = 2u, kIndexMask = (1u << 26) - 1u;
-                    uint32_t n_raw = 0, sn = 0, cn = 0, rn = 0;
-                    uint32_t* const rawq = queues;                                    // kQueueCap entries
-                    uint32_t* const clusterq = queues + kQueueCap;                    // kQueueCap
-                    uint32_t* const rootq = queues + 2u * kQueueCap;                  // kQueueCap
-                    uint32_t* const stack = queues + 3u * kQueueCap;                  // gen_cap + kStackReserve
+                    constexpr uint32_t kIndexMask = (1u << 26) - 1u;
+                    uint32_t sn = 0, cn = 0, rn = 0;
+                    uint32_t* const clusterq = queues;                                // kQueueCap entries
+                    uint32_t* const rootq = queues + kQueueCap;                       // kQueueCap
+                    uint32_t* const stack = queues + 2u * kQueueCap;                  // gen_cap + kStackReserve
                     const float4* const bxs = reinterpret_cast<const float4*>(P.boxes);
                     const uint32_t cluster_parent_first = P.box_cluster_parent_first;
                     for (;;) {
-                        int k = rn >= 64u ? 0 : cn >= 64u ? 1 : sn >= 64u ? 2 : n_raw >= 64u * kPer ? 3 : -1;
+                        int k = rn >= 64u ? 0 : cn >= 64u ? 1 : sn >= 64u ? 2 : -1;
                         if (k < 0) {
-                            if (total_rem != 0u && n_raw < kQueueCap) { n_raw += unpack(rawq + n_raw, kQueueCap - n_raw, 26u); continue; }
-                            k = n_raw != 0u ? 3 : sn != 0u ? 2 : cn != 0u ? 1 : rn != 0u ? 0 : -1;
+                            // the owners' filter: until two rounds' worth of survivors wait or nothing is left
+                            if (__any((nz | wm) != 0u)) {
+                                uint32_t& qn = levels == 1u ? cn : sn;
+                                uint32_t* const dst = levels == 1u ? clusterq : stack;
+                                // the next record of this lane's masks (0 and `false` when there is none)
+                                auto next_candidate = [&](uint32_t& node) -> bool {
+                                    const bool more = (nz | wm) != 0u;
+                                    node = 0u;
+                                    if (more) {
+                                        if (wm == 0u) {
+                                            const uint32_t cc = (uint32_t)__builtin_ctz(nz);
+                                            nz &= nz - 1u;
+                                            wm = masks[cc * 64u];
+                                            ebase = blk + cc * 2u * kChunk;
+                                        }
+                                        const uint32_t j = (uint32_t)__builtin_clz(wm);
+                                        wm ^= 0x80000000u >> j;
+                                        node = ebase + j;
+                                    }
+                                    return more;
+                                };
+                                // (one box ahead: the next trip's box is requested before this trip's is tested)
+                                uint32_t node;
+                                bool have = next_candidate(node);
+                                float4 b0 = bxs[2u * (size_t)node], b1 = bxs[2u * (size_t)node + 1u];
+                                bool again;
+                                do {
+                                    uint32_t node_n;
+                                    const bool have_n = next_candidate(node_n);
+                                    const float4 n0 = bxs[2u * (size_t)node_n], n1 = bxs[2u * (size_t)node_n + 1u];
+                                    const bool touch = box_may_touch<QUAD>(b0, b1, o, d);
+                                    const unsigned long long km = __builtin_amdgcn_ballot_w64(touch) & __builtin_amdgcn_ballot_w64(have);
+                                    if (touch && have) dst[qn + rank_in(km)] = (lane << 26) | node;
+                                    qn += (uint32_t)__popcll(km);
+                                    node = node_n; have = have_n; b0 = n0; b1 = n1;
+                                    again = __any(have);
+                                } while (again && qn < 128u);
+                                // (stopped with candidates fetched but not tested: they go back into the lane's mask word)
+                                if (have) { wm |= 0x80000000u >> (node - ebase); }
+                                lds_order();
+                                MRT_STAMP(6);
+                                continue;
+                            }
+                            k = sn != 0u ? 2 : cn != 0u ? 1 : rn != 0u ? 0 : -1;
                             if (k < 0) break;
                         }
                         if (k == 0) { root_round(rootq, rn); continue; }
-                        if (k == 3) {
-                            // filter round: up to 128 raw candidates, two per lane; the survivors become inner items (top
-                            // record j = node j) -- or cluster items where the top IS the cluster level (a one-level hierarchy)
-                            const uint32_t take = n_raw < 64u * kPer ? n_raw : 64u * kPer, start = n_raw - take;
-                            uint32_t it[kPer];
-                            bool keep[kPer];
-                            unsigned long long km[kPer];
-#pragma unroll
-                            for (uint32_t q = 0; q < kPer; q++) it[q] = rawq[(lane + 64u * q < take) ? start + lane + 64u * q : 0u];
-#pragma unroll
-                            for (uint32_t q = 0; q < kPer; q++) {
-                                const uint32_t owner = it[q] >> 26, node = it[q] & kIndexMask;
-                                const float4 r0 = rays[2u * owner];
-                                const float2 r1 = *reinterpret_cast<const float2*>(rays + 2u * owner + 1u);
-                                const float4* const bx = bxs + 2u * (size_t)node;
-                                keep[q] = box_may_touch<QUAD>(bx[0], bx[1], v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y)) && (lane + 64u * q < take);
-                                km[q] = __builtin_amdgcn_ballot_w64(keep[q]);
-                            }
-                            uint32_t* const dst = levels == 1u ? clusterq + cn : stack + sn;
-                            uint32_t kept = 0;
-#pragma unroll
-                            for (uint32_t q = 0; q < kPer; q++) {
-                                if (keep[q]) dst[kept + rank_in(km[q])] = it[q];
-                                kept += (uint32_t)__popcll(km[q]);
-                            }
-                            if (levels == 1u) cn += kept; else sn += kept;
-                            n_raw = start;
-                            lds_order();
-                            MRT_STAMP(2);           // (the stamps build books filter rounds under the node rounds' time)
-                            continue;
-                        }
                         const uint32_t n = k == 1 ? cn : sn;
                         uint32_t take = n < 64u ? n : 64u;
                         if (k == 2) {
@@ -1317,7 +1327,7 @@ void render_lds_layout(const KParams& p, uint32_t out[2]) {
 // the wave's work-stack capacity that makes a large scene's workgroup fit 4 per CU (160 KB / 4 groups / 4 waves per wave)
 uint32_t large_scene_stack_cap(uint32_t mask_chunks) {
     const uint32_t budget = 160u * 1024u / 4u / kWavesPerGroup;
-    const uint32_t fixed = lds_off_queues() + (kStackReserve + 3u * kQueueCap) * 4u + mask_chunks * 128u;
+    const uint32_t fixed = lds_off_queues() + (kStackReserve + 2u * kQueueCap) * 4u + mask_chunks * 128u;
     return (budget - fixed) / 4u;
 }
 

@@ -19,13 +19,11 @@ def _json(name):
     return json.load(open(os.path.join(ROOT, "profiles", name)))
 
 
-def _shard(pattern):
-    """(Msamples/s per GPU, lane utilisation) of the first line of profiles/r04_shard_throughput.txt matching `pattern`"""
-    for line in open(os.path.join(ROOT, "profiles", f"{R}_shard_throughput.txt")):
-        if re.search(pattern, line):
-            m = re.search(r"per-GPU ([\d.]+) Msamples/s, lane utilisation ([\d.]+)", line)
-            return float(m.group(1)), float(m.group(2))
-    raise KeyError(pattern)
+def _shard(pattern, nth=0):
+    """(Msamples/s per GPU, lane utilisation) of the nth line of profiles/r04_shard_throughput.txt matching `pattern`"""
+    hits = [line for line in open(os.path.join(ROOT, "profiles", f"{R}_shard_throughput.txt")) if re.search(pattern, line)]
+    m = re.search(r"per-GPU ([\d.]+) Msamples/s, lane utilisation ([\d.]+)", hits[nth])
+    return float(m.group(1)), float(m.group(2))
 
 
 def _phase(name, pattern):
@@ -52,6 +50,8 @@ TOKENS = {
     "C5_VALU": (lambda: _json(f"{R}_c5_pmc.json")["derived"]["valu_insts_per_wave_bounce"], ",.0f"),
     "C5_SALU": (lambda: _json(f"{R}_c5_pmc.json")["derived"]["salu_per_valu"], ".2f"),
     "C5_PARKED": (lambda: _json(f"{R}_c5_pmc.json")["derived"]["wave_cycles_parked_frac"], ".2f"),
+    "C5_WALL_ISSUE": (lambda: _json(f"{R}_bench_c5_n1.json")["valu_issue"]["frac_over_wall_time"], ".2f"),
+    "C3_WALL_ISSUE": (lambda: _json(f"{R}_bench_n1.json")["valu_issue"]["frac_over_wall_time"], ".2f"),
     "C1_VALUE": (lambda: _json(f"{R}_bench_c1_n1.json")["value"], ",.0f"),
     "C2_VALUE": (lambda: _json(f"{R}_bench_c2_n1.json")["value"], ",.0f"),
     "C4_VALUE": (lambda: _json(f"{R}_bench_c4_n1.json")["value"], ",.0f"),
@@ -61,6 +61,9 @@ TOKENS = {
     "INTERACTIVE_X32_VALUE": (lambda: _json(f"{R}_bench_interactive_x32_n1.json")["value"], ",.0f"),
     "SHARD8_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0")[0], ",.0f"),
     "SHARD8_UTIL": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0")[1], ".2f"),
+    # (the third 0/8 line of the file: the same share with round 3's schedule, MRT_SLOTS=2 -- see scripts/refresh_measurements.sh)
+    "SHARD8_OLD_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0", 1)[0], ",.0f"),
+    "SHARD8_OLD_UTIL": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0", 1)[1], ".2f"),
     "SHARD4_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/4 rng_mode 0")[0], ",.0f"),
     "SHARD2_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/2 rng_mode 0")[0], ",.0f"),
     "C4SHARD_VALUE": (lambda: _shard(r"^cover-glass 3840x2160x1024 shard 0/8 rng_mode 0")[0], ",.0f"),

@@ -80,6 +80,7 @@ if bench_line and "SQ_INSTS_VALU" in vals and key:
     vj[key] = {"issue_frac": out["derived"].get("valu_issue_utilisation_at_2cyc_per_inst"),
                "thread_utilisation": out["derived"].get("valu_thread_utilisation"),
                "valu_insts_per_wave_bounce": out["derived"]["valu_insts_per_wave_bounce"],
+               "valu_insts_per_launch": vals["SQ_INSTS_VALU"],          # deterministic for the workload: bench.py divides it by its own wall time
                "source": f"profiles/{rnd}_{tag}_pmc.json", "source_sha16": source_sha16()}
     vj["_note"] = "SQ counters per render_kernel launch from rocprofv3 --pmc passes of bench.py (scripts/profile.sh); bench.py copies them into valu.pmc_*"
     json.dump(vj, open(vj_path, "w"), indent=1, sort_keys=True)
