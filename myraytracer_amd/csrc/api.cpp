@@ -1168,8 +1168,8 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
     p.pilot_spp = c->pilot_spp;
     // Launch width and frames in flight (mrt_ctx::width_div): a change waits for the frames under way.
-    const bool adaptive = batch == 1 && c->waves_per_cu_override == 0 && c->frame_slots_override == 0 &&
-                          c->locals.samples_per_frame >= 4u && c->n_tiles != 0;
+    const bool adaptive = batch == 1 && c->waves_per_cu_override == 0 && c->frame_slots_override == 0 && c->n_tiles != 0 &&
+                          c->locals.samples_per_frame != 0u;
     {
         uint32_t want = c->frame_slots_override > 0 ? (uint32_t)c->frame_slots_override : 2u;
         if (adaptive) {
@@ -1186,6 +1186,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                 c->width_valid_from = c->frame_seq + std::max(2u, c->width_div);
                 c->stat_base.valid = c->stat_last.valid = false;
                 c->width_prev = 0; c->width_settled = false; c->width_timing = false;
+                c->slot_mult = 1; c->mult_prev = 1;
             }
             // The host may not run further ahead than the frames in flight: before a slot is used again, its previous frame's
             // render kernel has completed (a swap-chain's back-pressure; the GPU still holds a full set of frames, queued or
@@ -1209,7 +1210,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
             // A measurement window: from the first frame launched at the current width with the pipeline full, over
             // 2 x (frames in flight) + 2 frames -- their lane utilisation (the samples above) and, the calls being paced by
             // the completions (the back-pressure above), their rate on the host's clock.
-            const uint32_t in_flight = std::max(2u, c->width_div);
+            const uint32_t in_flight = std::max(2u, c->width_div) * c->slot_mult;
             const auto now = std::chrono::steady_clock::now();
             if (!c->width_settled && !c->width_timing && c->frame_seq >= c->width_valid_from) {
                 c->width_timing = true;
@@ -1220,28 +1221,34 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                 c->stat_last.seq > c->stat_base.seq && c->stat_last.slots > c->stat_base.slots && c->stat_last.hits >= c->stat_base.hits) {
                 const double util = (double)(c->stat_last.hits - c->stat_base.hits) / (double)(c->stat_last.slots - c->stat_base.slots);
                 const double rate = (double)(c->frame_seq - c->width_t0_seq) / std::max(1e-9, std::chrono::duration<double>(now - c->width_t0).count());
-                uint32_t next_div = c->width_div;
-                if (c->width_prev != 0) {                    // a trial ends: keep the narrower width only if it pays
-                    if (rate < 1.03 * c->width_prev_rate) { next_div = c->width_prev; c->width_settled = true; }
+                uint32_t next_div = c->width_div, next_mult = c->slot_mult;
+                if (c->width_prev != 0) {                    // a trial ends: keep the new setting only if it pays
+                    if (rate < 1.03 * c->width_prev_rate) { next_div = c->width_prev; next_mult = c->mult_prev; c->width_settled = true; }
                     c->width_prev = 0;
                 }
                 if (!c->width_settled) {
-                    // (narrower only while a launch's waves still get at least two tiles each)
+                    // narrower only while a launch's waves still get at least two tiles each (and not for chains of a few
+                    // bounces, whose launches have a width rule of their own, below); else more frames side by side
                     const uint32_t cand = c->width_div == 1u ? 4u : c->width_div * 2u;
-                    if (util < 0.95 && cand <= mrt_ctx::kMaxFrameSlots && (uint64_t)c->n_tiles * cand >= 2ull * c->n_waves && c->n_waves >= cand) {
+                    const bool can_narrow = c->locals.samples_per_frame >= 4u && cand <= mrt_ctx::kMaxFrameSlots &&
+                                            (uint64_t)c->n_tiles * cand >= 2ull * c->n_waves && c->n_waves >= cand;
+                    const bool can_add = in_flight * 2u <= mrt_ctx::kMaxFrameSlots;
+                    if (util < 0.95 && (can_narrow || can_add)) {
                         c->width_prev = c->width_div;
+                        c->mult_prev = c->slot_mult;
                         c->width_prev_rate = rate;
-                        next_div = cand;
+                        if (can_narrow) next_div = cand; else next_mult = c->slot_mult * 2u;
                     } else {
                         c->width_settled = true;
                     }
                 }
                 c->width_div = next_div;
+                c->slot_mult = next_mult;
                 c->width_timing = false;
-                c->width_valid_from = c->frame_seq + std::max(2u, next_div);       // (the frames at the old width drain first)
+                c->width_valid_from = c->frame_seq + std::max(2u, next_div) * next_mult;       // (the frames of the old setting drain first)
                 c->stat_base.valid = c->stat_last.valid = false;
             }
-            want = std::max(2u, c->width_div);
+            want = std::min(std::max(2u, c->width_div) * c->slot_mult, mrt_ctx::kMaxFrameSlots);
         }
         if (want != c->frame_slots) {
             HIP_TRY(c, sync_all(c));
@@ -1320,7 +1327,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     // iteration is shorter (1080p, 1 spp: 20 waves per CU 0.74 ms, 8 waves 0.42 ms; DESIGN_HISTORY.md round 3).
     uint32_t launch_waves = c->n_waves;
     if (chain_spp < 4u && c->waves_per_cu_override == 0) launch_waves = std::min(launch_waves, c->cus * 8u);
-    if (adaptive) launch_waves = std::max(c->n_waves / std::max(c->width_div, 1u), 1u);         // (above: launch width)
+    if (adaptive && chain_spp >= 4u) launch_waves = std::max(c->n_waves / std::max(c->width_div, 1u), 1u);         // (above: launch width)
     if (c->lpt_enabled && c->n_tiles > launch_waves && chain_spp >= 4u) {
         if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
             int pe = mrt::launch_render(p, true, launch_waves, S.stream, &c->last_launch[1]);

@@ -98,10 +98,14 @@ struct mrt_ctx {
     // price of a longer frame latency -- and they do not always pay (C3 / C4, 0.98 / 0.99 lane utilisation at full width, lose
     // 1-4 % at a half; C2 loses 4 % at a half and gains 18 % at a quarter).  So: width_div starts from what is known up front
     // (8 for a pixel-starved shard of long chains, 2 for large scenes, else 1); while the measured lane utilisation at the
-    // current width is below 0.95 a narrower width is TRIED (x 4 from full width, then x 2) and kept only if the measured
-    // frame rate rises by 3 %, else the previous width returns and stays.  Scheduling only: the images do not change.
+    // current width is below 0.95 a narrower width is TRIED (x 4 from full width, then x 2) -- or, where the frame has too few
+    // tiles to be launched any narrower, twice the frames in flight -- and kept only if the measured frame rate rises by 3 %,
+    // else the previous setting returns and stays.  Scheduling only: the images do not change.
     uint32_t width_div = 0;                         // 0 = not chosen yet for the current workload
-    uint32_t width_prev = 0;                        // the width a running trial would return to (0 = no trial)
+    uint32_t slot_mult = 1;                         // frames in flight = max(2, width_div) x slot_mult (<= kMaxFrameSlots): frames too
+                                                    // small or too short to fill the chip gain from more of them side by side
+                                                    // (C1: 1,450 tiles for 5,120 waves: 2 / 4 / 8 in flight 2,470 / 4,040 / 6,960 Msamples/s)
+    uint32_t width_prev = 0, mult_prev = 1;         // what a running trial would return to (width_prev 0 = no trial)
     bool width_settled = false;                     // no further trials for this workload
     double width_prev_rate = 0.0;                   // frames / s measured at width_prev
     uint64_t width_valid_from = 0;                  // frame_seq from which samples and timings belong to the current width
