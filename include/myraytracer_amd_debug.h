@@ -55,6 +55,13 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
  * k (1 <= k <= levels, the swept top last) start at box_base[k], parallel to that level's records. */
 int mrt_debug_build_boxes(const mrt_sphere* spheres, size_t n, uint32_t max_levels, uint32_t top_target, float* boxes_out,
                           size_t boxes_cap, uint32_t info[8]);
+/* The same boxes in the order the kernel walks them (what mrt_set_world uploads for a large scene): numbered top-down over the
+ * complete 4-ary tree below the n_top swept records -- depth t at o_t = n_top (4^t - 1) / 3, so that the children of node g,
+ * whatever its depth, are 4 g + n_top .. + 3; slots without a node hold never-hit boxes.  open != 0: every real box opened
+ * wide (the form mrt_debug_set_boxes(0) selects).  info[5] = {levels, n_boxes, n_top, first cluster-level node, first node
+ * whose children are clusters}. */
+int mrt_debug_build_boxes_top_down(const mrt_sphere* spheres, size_t n, uint32_t max_levels, uint32_t top_target, int open,
+                                   float* boxes_out, size_t boxes_cap, uint32_t info[5]);
 /* Host-side diagnostic, no GPU needed: the ray-side factors of the matrix-core sweep for a scene and camera that keep every
  * ray origin and every bound within `reach` of the sweep's origin: scale_out[4] = {stretch K, 2 K^2,
  * -(1 - 2^-13) K^2, (4 reach)^2} with K the power of two for which |K oc.ds| <= 1/2 for every admitted ray, and

@@ -30,7 +30,7 @@ EXPORTS = [
     "mrt_last_error", "mrt_status_string", "mrt_abi_version", "mrt_build_id", "mrt_scene_default", "mrt_scene_cover",
     "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
     "mrt_srgb8", "mrt_write_png", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
-    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit", "mrt_debug_set_frame_batching", "mrt_debug_set_gather_per_band", "mrt_debug_arith", "mrt_debug_arith_pairs", "mrt_debug_set_boxes", "mrt_debug_build_boxes", "mrt_set_draw_counting", "mrt_debug_last_launch", "mrt_debug_set_frames_in_flight", "mrt_debug_lds_layout",
+    "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit", "mrt_debug_set_frame_batching", "mrt_debug_set_gather_per_band", "mrt_debug_arith", "mrt_debug_arith_pairs", "mrt_debug_set_boxes", "mrt_debug_build_boxes", "mrt_set_draw_counting", "mrt_debug_last_launch", "mrt_debug_set_frames_in_flight", "mrt_debug_lds_layout", "mrt_debug_build_boxes_top_down",
 ]
 
 
@@ -256,6 +256,7 @@ def load():
         "mrt_debug_last_launch": (i32, [vp, P(u32)]),
         "mrt_debug_set_frames_in_flight": (i32, [vp, i32]),
         "mrt_debug_lds_layout": (i32, [u32, u32, u32, u32, P(u32)]),
+        "mrt_debug_build_boxes_top_down": (i32, [vp, sz, u32, u32, i32, vp, sz, vp]),
     }
     assert sorted(sig) == sorted(EXPORTS)
     for name, (res, args) in sig.items():

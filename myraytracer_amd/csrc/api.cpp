@@ -1182,7 +1182,14 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                 // a half (their pixels' chains differ 10 x; every large scene measured gains or stays within 1 %).
                 const bool starved = !counter && c->locals.samples_per_frame >= 64u && (uint64_t)c->n_tiles < 2ull * c->n_waves &&
                                      c->n_tiles > c->n_waves / mrt_ctx::kMaxFrameSlots;
-                c->width_div = starved ? mrt_ctx::kMaxFrameSlots : (!counter && c->n_members > 1024u && c->n_tiles >= 4u * c->n_waves) ? 2u : 1u;
+                // Chains of a few bounces (the reference's default: ONE sample per frame): a frame is bound by its longest
+                // path -- up to ray_depth wave-iterations in sequence -- not by throughput, and every iteration is shorter
+                // with fewer resident waves (round 3: 20 / 8 waves per CU 0.74 / 0.42 ms per 1080p frame): a quarter of
+                // the waves, four frames side by side (round 4: 8 frames on 4 waves per CU each 9,030 Msamples/s against
+                // 4,990 for 2 on 8; the controller goes on from here).
+                const bool short_chains = c->locals.samples_per_frame < 4u && (uint64_t)c->n_tiles * 4u >= 2ull * c->n_waves;
+                c->width_div = starved ? mrt_ctx::kMaxFrameSlots : short_chains ? 4u :
+                               (!counter && c->n_members > 1024u && c->n_tiles >= 4u * c->n_waves) ? 2u : 1u;
                 c->width_valid_from = c->frame_seq + std::max(2u, c->width_div);
                 c->stat_base.valid = c->stat_last.valid = false;
                 c->width_prev = 0; c->width_settled = false; c->width_timing = false;
@@ -1227,11 +1234,9 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                     c->width_prev = 0;
                 }
                 if (!c->width_settled) {
-                    // narrower only while a launch's waves still get at least two tiles each (and not for chains of a few
-                    // bounces, whose launches have a width rule of their own, below); else more frames side by side
+                    // narrower only while a launch's waves still get at least two tiles each; else more frames side by side
                     const uint32_t cand = c->width_div == 1u ? 4u : c->width_div * 2u;
-                    const bool can_narrow = c->locals.samples_per_frame >= 4u && cand <= mrt_ctx::kMaxFrameSlots &&
-                                            (uint64_t)c->n_tiles * cand >= 2ull * c->n_waves && c->n_waves >= cand;
+                    const bool can_narrow = cand <= mrt_ctx::kMaxFrameSlots && (uint64_t)c->n_tiles * cand >= 2ull * c->n_waves && c->n_waves >= cand;
                     const bool can_add = in_flight * 2u <= mrt_ctx::kMaxFrameSlots;
                     if (util < 0.95 && (can_narrow || can_add)) {
                         c->width_prev = c->width_div;
@@ -1322,12 +1327,11 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     // With no more tiles than persistent waves every tile starts at once and the order cannot matter: no pilot, no sort.
     // ... nor when a pixel's chain is a handful of bounces (fewer than 4 samples per pixel and launch): three launches saved.
     const uint32_t chain_spp = c->locals.samples_per_frame * p.lane_frames;
-    // A launch whose pixel chains are a handful of bounces (the reference's default: ONE frame of 1 sample per pixel) is bound
-    // by its longest path -- up to ray_depth wave-iterations in sequence -- not by throughput: with fewer resident waves every
-    // iteration is shorter (1080p, 1 spp: 20 waves per CU 0.74 ms, 8 waves 0.42 ms; DESIGN_HISTORY.md round 3).
+    // (launches outside the controller's reach -- batches, overrides -- whose chains are a handful of bounces: 8 waves per CU,
+    // round 3's rule for such frames)
     uint32_t launch_waves = c->n_waves;
     if (chain_spp < 4u && c->waves_per_cu_override == 0) launch_waves = std::min(launch_waves, c->cus * 8u);
-    if (adaptive && chain_spp >= 4u) launch_waves = std::max(c->n_waves / std::max(c->width_div, 1u), 1u);         // (above: launch width)
+    if (adaptive) launch_waves = std::max(c->n_waves / std::max(c->width_div, 1u), 1u);         // (above: launch width)
     if (c->lpt_enabled && c->n_tiles > launch_waves && chain_spp >= 4u) {
         if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
             int pe = mrt::launch_render(p, true, launch_waves, S.stream, &c->last_launch[1]);
@@ -1490,6 +1494,27 @@ int mrt_debug_build_hierarchy(const mrt_sphere* spheres, size_t n, uint32_t max_
     if (member_index_out) std::memcpy(member_index_out, h.member_index.data(), h.member_index.size() * sizeof(uint32_t));
     if (mfma_out) std::memcpy(mfma_out, mf.data(), mf.size() * sizeof(uint16_t));
     if (mfma_origin_out) for (int k = 0; k < 3; k++) mfma_origin_out[k] = origin[k];
+    return MRT_OK;
+}
+
+int mrt_debug_build_boxes_top_down(const mrt_sphere* spheres, size_t n, uint32_t max_levels, uint32_t top_target, int open,
+                                   float* boxes_out, size_t boxes_cap, uint32_t info[5]) {
+    if ((!spheres && n) || !info || max_levels < 1 || max_levels > mrt::kMaxLevels || n > mrt::kMaxSpheres)
+        return MRT_ERR_INVALID_ARG;
+    std::vector<float> centers(4 * (n ? n : 1)), radii(n ? n : 1);
+    for (size_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) centers[4 * i + k] = spheres[i].center[k];
+        centers[4 * i + 3] = 1.0f;
+        radii[i] = spheres[i].radius;
+    }
+    Hierarchy h;
+    build_hierarchy(centers.data(), radii.data(), (uint32_t)n, 8.0f, max_levels, top_target, h);
+    std::vector<mrt::BoxRec> dev;
+    uint32_t cf = 0, cpf = 0;
+    boxes_top_down(h, open != 0, dev, &cf, &cpf);
+    info[0] = h.levels; info[1] = (uint32_t)dev.size(); info[2] = (uint32_t)h.top.size(); info[3] = cf; info[4] = cpf;
+    if (boxes_out && boxes_cap < dev.size()) return MRT_ERR_TOO_SMALL;
+    if (boxes_out) std::memcpy(boxes_out, dev.data(), dev.size() * sizeof(mrt::BoxRec));
     return MRT_OK;
 }
 

@@ -97,7 +97,7 @@ struct mrt_ctx {
     // launch's tail, in which lanes idle until their wave's longest pixel ends, is the same length but a smaller share) at the
     // price of a longer frame latency -- and they do not always pay (C3 / C4, 0.98 / 0.99 lane utilisation at full width, lose
     // 1-4 % at a half; C2 loses 4 % at a half and gains 18 % at a quarter).  So: width_div starts from what is known up front
-    // (8 for a pixel-starved shard of long chains, 2 for large scenes, else 1); while the measured lane utilisation at the
+    // (8 for a pixel-starved shard of long chains, 4 for chains of a few bounces, 2 for large scenes, else 1); while the measured lane utilisation at the
     // current width is below 0.95 a narrower width is TRIED (x 4 from full width, then x 2) -- or, where the frame has too few
     // tiles to be launched any narrower, twice the frames in flight -- and kept only if the measured frame rate rises by 3 %,
     // else the previous setting returns and stays.  Scheduling only: the images do not change.

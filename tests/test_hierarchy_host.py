@@ -280,3 +280,43 @@ def test_lds_footprint_keeps_the_residency_the_kernels_are_built_for(mrt):
     for n_side, levels, target in [(36, 4, 0), (36, 1, 64), (50, 2, 8), (70, 4, 16), (100, 3, 256)]:
         h, lds, groups, cap = layout(mrt.scene_stress(2, n_side)[0], levels, target)
         assert groups == 4 and lds * 4 <= 160 * 1024 and cap >= 400, (n_side, levels, target, lds, groups, cap)
+
+
+def test_the_kernels_top_down_numbering_of_the_boxes(mrt):
+    """The large-scene walk addresses boxes by ONE rule -- the children of node g are 4 g + n_top .. + 3, whatever g's level
+    (kernels.hip) -- over the array api.cpp's boxes_top_down lays out.  Against the level-ordered boxes of
+    mrt_debug_build_boxes: every node sits where the rule puts it (top record j at j; child q of the node at level k, index j,
+    at 4 g + n_top + q), every other slot is a never-hit box, the cluster level and its parents start where the kernel is
+    told, and the opened-wide copy differs only in the extents of real boxes."""
+    L = _lib.load()
+    for name, sc in scenes(mrt):
+        for max_levels, target in [(4, 0), (4, 16), (3, 8), (2, 64), (1, 64)]:
+            b = build_boxes(mrt, sc, max_levels, target)
+            info = (C.c_uint32 * 5)()
+            assert L.mrt_debug_build_boxes_top_down(sc.ctypes.data, len(sc), max_levels, target, 0, None, 0, info) == 0
+            levels, n_dev, n_top, cluster_first, cluster_parent_first = (int(x) for x in info)
+            assert levels == b["levels"] and n_top % 32 == 0
+            dev = np.zeros((n_dev, 8), np.float32)
+            wide = np.zeros((n_dev, 8), np.float32)
+            assert L.mrt_debug_build_boxes_top_down(sc.ctypes.data, len(sc), max_levels, target, 0, dev.ctypes.data, n_dev, info) == 0
+            assert L.mrt_debug_build_boxes_top_down(sc.ctypes.data, len(sc), max_levels, target, 1, wide.ctypes.data, n_dev, info) == 0
+            o = [n_top * (4 ** t - 1) // 3 for t in range(levels + 1)]
+            assert n_dev == o[levels] and cluster_first == o[levels - 1] and cluster_parent_first == (o[levels - 2] if levels >= 2 else 0)
+            placed = np.zeros(n_dev, bool)
+            host, base = b["boxes"], b["base"]
+            for t in range(levels):
+                k = levels - t                               # the level at depth t
+                first = base[k]
+                last = base[k + 1] if k < levels else len(host)
+                for j in range(last - first):
+                    g = o[t] + j
+                    assert np.array_equal(dev[g].view(np.uint32), host[first + j].view(np.uint32)), (name, k, j)
+                    placed[g] = True
+                    if t + 1 < levels and host[first + j][3] >= 0:          # a real node: its children by the kernel's rule
+                        kids = base[k - 1] + 4 * j
+                        for q in range(4):
+                            assert np.array_equal(dev[4 * g + n_top + q].view(np.uint32), host[kids + q].view(np.uint32)), (name, k, j, q)
+            assert (dev[~placed][:, 3:6] == np.float32(-3.0e38)).all(), name          # never-hit everywhere else
+            real = dev[:, 3] >= 0
+            assert np.array_equal(wide[~real].view(np.uint32), dev[~real].view(np.uint32))
+            assert (wide[real][:, 3:6] == np.float32(3.0e37)).all() and np.array_equal(wide[real][:, [0, 1, 2, 6, 7]], dev[real][:, [0, 1, 2, 6, 7]])
