@@ -176,7 +176,7 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 // -3e38: some axis' right-hand side is then hugely negative (a unit direction has a component >= 0.57).
 // 24 VALU: 3 + 3 (X) + 1 (K) + 3 x 5 + 2.
 template <bool QUAD>
-__device__ __forceinline__ bool box_may_touch(const float4 b0, const float4 b1, V3 o, V3 d) {
+__device__ __forceinline__ uint32_t box_separated_bits(const float4 b0, const float4 b1, V3 o, V3 d) {
     const float px = o.x - b0.x, py = o.y - b0.y, pz = o.z - b0.z;
     const float X = QUAD ? __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px))
                          : (__builtin_fabsf(px) + __builtin_fabsf(py)) + __builtin_fabsf(pz);
@@ -186,8 +186,12 @@ __device__ __forceinline__ bool box_may_touch(const float4 b0, const float4 b1, 
     const float sx = __builtin_fmaf(ey, adz, __builtin_fmaf(ez, ady, K)) - __builtin_fabsf(__builtin_fmaf(-pz, d.y, py * d.z));
     const float sy = __builtin_fmaf(ez, adx, __builtin_fmaf(ex, adz, K)) - __builtin_fabsf(__builtin_fmaf(-px, d.z, pz * d.x));
     const float sz = __builtin_fmaf(ex, ady, __builtin_fmaf(ey, adx, K)) - __builtin_fabsf(__builtin_fmaf(-py, d.x, px * d.y));
-    // separated on some axis <=> some difference is negative (finite operands: never NaN)
-    return (int32_t)(__float_as_uint(sx) | __float_as_uint(sy) | __float_as_uint(sz)) >= 0;
+    // separated on some axis <=> some difference is negative (finite operands: never NaN): the sign bit of the result
+    return __float_as_uint(sx) | __float_as_uint(sy) | __float_as_uint(sz);
+}
+template <bool QUAD>
+__device__ __forceinline__ bool box_may_touch(const float4 b0, const float4 b1, V3 o, V3 d) {
+    return (int32_t)box_separated_bits<QUAD>(b0, b1, o, d) >= 0;
 }
 
 // ---- the same conservative test on the matrix cores -------------------------------------------------
@@ -843,13 +847,15 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         if (k < 0) {
                             // the owners' filter: until two rounds' worth of survivors wait or nothing is left
                             if (__any((nz | wm) != 0u)) {
-                                uint32_t& qn = levels == 1u ? cn : sn;
+                                // (the queue's fill in a variable of its own: as a reference to `cn` or `sn` it made hipcc treat both
+                                // -- and with them the whole round scheduling below -- as per-lane values in VGPRs)
+                                uint32_t qn = levels == 1u ? cn : sn;
                                 uint32_t* const dst = levels == 1u ? clusterq : stack;
-                                // the next record of this lane's masks (0 and `false` when there is none)
-                                auto next_candidate = [&](uint32_t& node) -> bool {
-                                    const bool more = (nz | wm) != 0u;
-                                    node = 0u;
-                                    if (more) {
+                                const uint32_t owner_bits = lane << 26;
+                                // the next record of this lane's masks with bit 31 set, or 0 when the lane has none left
+                                auto next_candidate = [&]() -> uint32_t {
+                                    uint32_t code = 0u;
+                                    if ((nz | wm) != 0u) {
                                         if (wm == 0u) {
                                             const uint32_t cc = (uint32_t)__builtin_ctz(nz);
                                             nz &= nz - 1u;
@@ -858,28 +864,43 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                         }
                                         const uint32_t j = (uint32_t)__builtin_clz(wm);
                                         wm ^= 0x80000000u >> j;
-                                        node = ebase + j;
+                                        code = 0x80000000u | (ebase + j);
                                     }
-                                    return more;
+                                    return code;
                                 };
-                                // (one box ahead: the next trip's box is requested before this trip's is tested)
-                                uint32_t node;
-                                bool have = next_candidate(node);
-                                float4 b0 = bxs[2u * (size_t)node], b1 = bxs[2u * (size_t)node + 1u];
-                                bool again;
-                                do {
-                                    uint32_t node_n;
-                                    const bool have_n = next_candidate(node_n);
-                                    const float4 n0 = bxs[2u * (size_t)node_n], n1 = bxs[2u * (size_t)node_n + 1u];
-                                    const bool touch = box_may_touch<QUAD>(b0, b1, o, d);
-                                    const unsigned long long km = __builtin_amdgcn_ballot_w64(touch) & __builtin_amdgcn_ballot_w64(have);
-                                    if (touch && have) dst[qn + rank_in(km)] = (lane << 26) | node;
+                                auto fetch_box = [&](const uint32_t code, float4& b0, float4& b1) {
+                                    const size_t g = code & 0x7FFFFFFFu;
+                                    b0 = bxs[2u * g];
+                                    b1 = bxs[2u * g + 1u];
+                                };
+                                // a candidate whose box the ray's line may touch goes on the queue (one comparison decides both: the
+                                // separation's sign bit, or the missing candidate bit)
+                                auto test_push = [&](const uint32_t code, const float4 b0, const float4 b1) {
+                                    const bool keep = (int32_t)(box_separated_bits<QUAD>(b0, b1, o, d) | ~code) >= 0;
+                                    const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+                                    if (keep) dst[qn + rank_in(km)] = owner_bits | (code & 0x7FFFFFFFu);
                                     qn += (uint32_t)__popcll(km);
-                                    node = node_n; have = have_n; b0 = n0; b1 = n1;
-                                    again = __any(have);
-                                } while (again && qn < 128u);
-                                // (stopped with candidates fetched but not tested: they go back into the lane's mask word)
-                                if (have) { wm |= 0x80000000u >> (node - ebase); }
+                                };
+                                auto some_left = [&](const uint32_t code) -> bool { return __builtin_amdgcn_ballot_w64((int32_t)code < 0) != 0ull; };
+                                // One box ahead: the next trip's box is requested before this trip's is tested.  Two trips per turn of
+                                // the loop, on alternating register sets: carried over a single-trip loop the box fetched ahead had to be
+                                // COPIED at the end of every trip, which also waited for it there
+                                uint32_t ca = next_candidate(), cb, left;
+                                float4 a0, a1, b0, b1;
+                                fetch_box(ca, a0, a1);
+                                for (;;) {
+                                    cb = next_candidate();
+                                    fetch_box(cb, b0, b1);
+                                    test_push(ca, a0, a1);
+                                    if (!(some_left(cb) && qn < 128u)) { left = cb; break; }
+                                    ca = next_candidate();
+                                    fetch_box(ca, a0, a1);
+                                    test_push(cb, b0, b1);
+                                    if (!(some_left(ca) && qn < 128u)) { left = ca; break; }
+                                }
+                                // (stopped with a candidate fetched but not tested: it goes back into the lane's mask word)
+                                if ((int32_t)left < 0) wm |= 0x80000000u >> ((left & 0x7FFFFFFFu) - ebase);
+                                if (levels == 1u) cn = qn; else sn = qn;
                                 lds_order();
                                 MRT_STAMP(6);
                                 continue;
