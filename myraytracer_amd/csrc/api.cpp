@@ -1133,7 +1133,8 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     }
     p.levels = c->levels; p.n_nodes = c->n_nodes; p.n_members = c->n_members;
     // small scenes: the top queue holds a ray's candidates among ALL top records; large scenes: the wave's one work stack
-    p.gen_cap = c->n_members <= 1024u ? 576u : mrt::large_scene_stack_cap(p.mask_chunks);
+    p.box_lds_count = c->n_members <= 1024u ? 0u : mrt::large_scene_box_lds_count(c->n_padded, c->levels, p.mask_chunks, mrt::kBoxLdsCap);
+    p.gen_cap = c->n_members <= 1024u ? 576u : mrt::large_scene_stack_cap(p.mask_chunks, p.box_lds_count);
     for (uint32_t k = 0; k < mrt::kMaxLevels; k++) p.level_base[k] = c->level_base[k];
     // large scenes only (kernels.hip: !SMALL): every node's box, in the kernel's top-down numbering
     p.boxes = c->boxes_mode == 0 ? c->d_boxes_open : c->d_boxes;
@@ -1651,7 +1652,8 @@ int mrt_debug_lds_layout(uint32_t n_members, uint32_t n_nodes, uint32_t levels, 
     std::memset(&p, 0, sizeof p);
     p.n_members = n_members; p.n_nodes = n_nodes; p.levels = levels; p.n_padded = n_top_padded;
     { const uint32_t ch = (n_top_padded + mrt::kChunk - 1) / mrt::kChunk; p.mask_chunks = ch < 16u ? ch : 16u; }
-    p.gen_cap = n_members <= 1024u ? 576u : mrt::large_scene_stack_cap(p.mask_chunks);
+    p.box_lds_count = n_members <= 1024u ? 0u : mrt::large_scene_box_lds_count(n_top_padded, levels, p.mask_chunks, mrt::kBoxLdsCap);
+    p.gen_cap = n_members <= 1024u ? 576u : mrt::large_scene_stack_cap(p.mask_chunks, p.box_lds_count);
     uint32_t lay[2];
     mrt::render_lds_layout(p, lay);
     out[0] = lay[0]; out[1] = lay[1]; out[2] = p.gen_cap;

@@ -417,7 +417,11 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     const uint32_t levels = SMALL ? 1u : P.levels;
     // (small scenes: the member records, then their sphere indices as u16 -- what a root round reads per item; from L2 the
     // index was a dependent global load in the middle of every root round)
-    const uint32_t nodes_bytes = SMALL ? P.n_nodes * (uint32_t)sizeof(SphereRec) + lds_index_bytes(P.n_members) : 0u;
+    // (large scenes: the first P.box_lds_count boxes of the top-down numbering -- the swept top, and the level below it where it
+    // fits -- which every owner's filter and the first inner rounds read: from L1 they were a third of the kernel's vector
+    // memory instructions, and the texture path, not the VALU, is what a large scene's rounds wait for)
+    const uint32_t nodes_bytes = SMALL ? P.n_nodes * (uint32_t)sizeof(SphereRec) + lds_index_bytes(P.n_members)
+                                       : P.box_lds_count * (uint32_t)sizeof(BoxRec);
     unsigned char* const wlds = lds_raw + nodes_bytes + wave * lds_wave_bytes(SMALL, levels, P.gen_cap, P.mask_chunks);
     // lane l's 32 bytes: (ox,oy,oz,dx) (dy,dz) and the u64 slot its closest hit is min-ed into
     float4* const rays = reinterpret_cast<float4*>(wlds + lds_off_rays());
@@ -432,6 +436,11 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
         for (uint32_t i = threadIdx.x; i < n_rec; i += 64u * kWavesPerGroup) dst[i] = P.nodes[i];
         uint16_t* const di = reinterpret_cast<uint16_t*>(lds_raw + n_rec * (uint32_t)sizeof(SphereRec));
         for (uint32_t i = threadIdx.x; i < P.n_members; i += 64u * kWavesPerGroup) di[i] = (uint16_t)P.member_index[i];   // < 1,024 spheres
+        __syncthreads();
+    } else {
+        float4* const dst = reinterpret_cast<float4*>(lds_raw);
+        const float4* const src = reinterpret_cast<const float4*>(P.boxes);
+        for (uint32_t i = threadIdx.x; i < 2u * P.box_lds_count; i += 64u * kWavesPerGroup) dst[i] = src[i];
         __syncthreads();
     }
 
@@ -840,7 +849,16 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     uint32_t* const clusterq = queues;                                // kQueueCap entries
                     uint32_t* const rootq = queues + kQueueCap;                       // kQueueCap
                     uint32_t* const stack = queues + 2u * kQueueCap;                  // gen_cap + kStackReserve
-                    const float4* const bxs = reinterpret_cast<const float4*>(P.boxes);
+                    // its first box_lds boxes, in LDS (address-space qualified: as two generic pointers hipcc merged the owners' two
+                    // sources into ONE flat load of a selected pointer, which goes down the texture path whatever it reads)
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    typedef const f32x4 __attribute__((address_space(3)))* LdsBoxPtr;
+                    typedef const f32x4 __attribute__((address_space(1)))* GlobalBoxPtr;
+                    auto f4 = [](const f32x4 v) { return make_float4(v.x, v.y, v.z, v.w); };
+                    const LdsBoxPtr bxs_lds = (LdsBoxPtr)lds_raw;
+                    const GlobalBoxPtr bxs_g = (GlobalBoxPtr)P.boxes;
+                    const uint32_t box_lds = P.box_lds_count;
+                    const bool top_in_lds = box_lds >= n_padded;
                     const uint32_t cluster_parent_first = P.box_cluster_parent_first;
                     for (;;) {
                         int k = rn >= 64u ? 0 : cn >= 64u ? 1 : sn >= 64u ? 2 : -1;
@@ -869,9 +887,9 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                     return code;
                                 };
                                 auto fetch_box = [&](const uint32_t code, float4& b0, float4& b1) {
-                                    const size_t g = code & 0x7FFFFFFFu;
-                                    b0 = bxs[2u * g];
-                                    b1 = bxs[2u * g + 1u];
+                                    const uint32_t g = code & 0x7FFFFFFFu;
+                                    if (top_in_lds) { b0 = f4(bxs_lds[2u * g]); b1 = f4(bxs_lds[2u * g + 1u]); }
+                                    else { b0 = f4(bxs_g[2u * (size_t)g]); b1 = f4(bxs_g[2u * (size_t)g + 1u]); }
                                 };
                                 // a candidate whose box the ray's line may touch goes on the queue (one comparison decides both: the
                                 // separation's sign bit, or the missing candidate bit)
@@ -930,8 +948,17 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                             if (!PILOT) mtests += kClusterK * take;
                         } else {
                             const uint32_t c0 = 4u * g + n_padded;                    // the first child, in the same numbering
-                            const float4* const bx = bxs + 2u * (size_t)c0;
-                            const float4 b[8] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], bx[6], bx[7]};
+                            // (from LDS when the children of every item of the round are among the boxes held there)
+                            float4 b[8];
+                            if (__builtin_amdgcn_ballot_w64(act && c0 + 4u > box_lds) == 0ull) {
+                                const LdsBoxPtr bx = bxs_lds + 2u * c0;
+#pragma unroll
+                                for (int q = 0; q < 8; q++) b[q] = f4(bx[q]);
+                            } else {
+                                const GlobalBoxPtr bx = bxs_g + 2u * (size_t)c0;
+#pragma unroll
+                                for (int q = 0; q < 8; q++) b[q] = f4(bx[q]);
+                            }
                             bool h[4];
                             unsigned long long hm[4];
                             const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(act);
@@ -1331,7 +1358,7 @@ __global__ void __launch_bounds__(256) fill_seeds_kernel(uint32_t* seeds, uint64
 // SMALL scenes (every node id < 1024): member records live in LDS and work items are u16
 static bool scene_is_small(const KParams& p) { return p.n_members <= 1024u; }
 static uint32_t group_lds_bytes(const KParams& p, bool small) {
-    return (small ? p.n_nodes * (uint32_t)sizeof(SphereRec) + lds_index_bytes(p.n_members) : 0u) +
+    return (small ? p.n_nodes * (uint32_t)sizeof(SphereRec) + lds_index_bytes(p.n_members) : p.box_lds_count * (uint32_t)sizeof(BoxRec)) +
            kWavesPerGroup * lds_wave_bytes(small, p.levels, p.gen_cap, p.mask_chunks);
 }
 
@@ -1345,11 +1372,22 @@ void render_lds_layout(const KParams& p, uint32_t out[2]) {
     out[0] = lds;
     out[1] = per_cu;
 }
-// the wave's work-stack capacity that makes a large scene's workgroup fit 4 per CU (160 KB / 4 groups / 4 waves per wave)
-uint32_t large_scene_stack_cap(uint32_t mask_chunks) {
-    const uint32_t budget = 160u * 1024u / 4u / kWavesPerGroup;
+// large scenes: how many leading boxes the workgroup keeps in LDS (mrt_internal.h)
+uint32_t large_scene_box_lds_count(uint32_t n_top_padded, uint32_t levels, uint32_t mask_chunks, uint32_t cap) {
+    // the most that leaves every wave a work stack of kMinStack entries: top + the level below, the top alone, or nothing
+    constexpr uint32_t kMinStack = 480;
+    const uint32_t both = levels >= 2u ? 5u * n_top_padded : n_top_padded;
+    if (both <= cap && large_scene_stack_cap(mask_chunks, both) >= kMinStack) return both;
+    if (n_top_padded <= cap && large_scene_stack_cap(mask_chunks, n_top_padded) >= kMinStack) return n_top_padded;
+    return 0u;
+}
+// the wave's work-stack capacity that makes a large scene's workgroup fit 4 per CU (160 KB / 4 groups, minus the boxes the group
+// shares, / 4 waves); a multiple of 4 entries, so that every wave's LDS starts 16-byte aligned
+uint32_t large_scene_stack_cap(uint32_t mask_chunks, uint32_t box_lds_count) {
+    const uint32_t group = 160u * 1024u / 4u, shared = box_lds_count * (uint32_t)sizeof(BoxRec);
     const uint32_t fixed = lds_off_queues() + (kStackReserve + 2u * kQueueCap) * 4u + mask_chunks * 128u;
-    return (budget - fixed) / 4u;
+    if (shared >= group || (group - shared) / kWavesPerGroup <= fixed) return 0u;
+    return (((group - shared) / kWavesPerGroup - fixed) / 4u) & ~3u;
 }
 
 // the persistent render waves (pilot: + its cost-only finalize) on `stream`

@@ -79,6 +79,9 @@ struct KParams {
     // the capacity of the wave's work stack.  Null / 0 for small scenes.
     const BoxRec* boxes;
     uint32_t box_cluster_first, box_cluster_parent_first, box_quad;
+    // the first box_lds_count boxes of that numbering (the swept top, and the level below it where it fits) are copied into
+    // the workgroup's LDS: what the owners' filter and the first inner rounds read (kernels.hip)
+    uint32_t box_lds_count;
     // Spheres far larger than the rest (a ground sphere) are candidates for nearly every ray: up to kMaxDirect
     // of them stay out of the hierarchy and every ray evaluates their discriminant itself, from SGPRs.
     // They are the members direct_first .. direct_first + n_direct - 1 of level 0.
@@ -134,7 +137,11 @@ int render_waves_per_cu(int* out);
 // host only: {LDS bytes of one render workgroup, workgroups per CU} for p's scene layout; the work-stack capacity (entries)
 // of a large scene's wave with `mask_chunks` chunks of candidate masks
 void render_lds_layout(const KParams& p, uint32_t out[2]);
-uint32_t large_scene_stack_cap(uint32_t mask_chunks);
+uint32_t large_scene_stack_cap(uint32_t mask_chunks, uint32_t box_lds_count);
+// how many leading boxes of the top-down numbering a large scene's workgroup keeps in LDS: the top level (n_top padded records)
+// and the 4 n_top slots of the level below, or the top alone, or none -- the most that leaves the waves their work stacks
+uint32_t large_scene_box_lds_count(uint32_t n_top_padded, uint32_t levels, uint32_t mask_chunks, uint32_t cap);
+constexpr uint32_t kBoxLdsCap = 1024;    // never more boxes (32 B each) than this in a workgroup's LDS
 // tile_order.hip: order[] = tile ids sorted by cost[] descending (bucket sort; ties in any order).
 // scratch: 1024 u32.
 int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, uint32_t n_tiles, void* stream);
