@@ -818,7 +818,7 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
         if (hipEventCreate(&c->ev_start[i]) != hipSuccess || hipEventCreate(&c->ev_stop[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
     if (hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) { c->err = "counter allocation failed"; return bail(MRT_ERR_HIP); }
-    if (hipHostMalloc((void**)&c->h_stats, 2 * mrt_ctx::kMaxFrameSlots * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { c->err = "pinned allocation failed"; return bail(MRT_ERR_HIP); }
+    if (hipHostMalloc((void**)&c->h_stats, 3 * mrt_ctx::kMaxFrameSlots * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { c->err = "pinned allocation failed"; return bail(MRT_ERR_HIP); }
     int st = alloc_frame_buffers(c);
     if (st != MRT_OK) return bail(st);
     *out = c;
@@ -1194,6 +1194,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                 c->width_valid_from = c->frame_seq + std::max(2u, c->width_div);
                 c->stat_base.valid = c->stat_last.valid = false;
                 c->width_prev = 0; c->width_settled = false; c->width_timing = false;
+                c->width_low_windows = 0;
                 c->slot_mult = 1; c->mult_prev = 1;
             }
             // The host may not run further ahead than the frames in flight: before a slot is used again, its previous frame's
@@ -1210,7 +1211,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                 if (!T.stats_pending || hipEventQuery(T.stats_ready) != hipSuccess) continue;
                 T.stats_pending = false;
                 if (T.stats_seq < c->width_valid_from) continue;
-                mrt_ctx::LaneStat st{T.stats_seq, c->h_stats[2 * i], c->h_stats[2 * i + 1], true};
+                mrt_ctx::LaneStat st{T.stats_seq, c->h_stats[3 * i], c->h_stats[3 * i + 2], true};
                 if (!c->stat_base.valid || st.seq < c->stat_base.seq) c->stat_base = st;
                 if (!c->stat_last.valid || st.seq > c->stat_last.seq) c->stat_last = st;
             }
@@ -1230,6 +1231,10 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                 const double util = (double)(c->stat_last.hits - c->stat_base.hits) / (double)(c->stat_last.slots - c->stat_base.slots);
                 const double rate = (double)(c->frame_seq - c->width_t0_seq) / std::max(1e-9, std::chrono::duration<double>(now - c->width_t0).count());
                 uint32_t next_div = c->width_div, next_mult = c->slot_mult;
+                static const bool trace = std::getenv("MRT_TRACE_WIDTH") != nullptr;      // diagnostics: every decision, on stderr
+                if (trace) std::fprintf(stderr, "mrt width: frame %u: div %u x %u, window %u frames, utilisation %.4f, %.2f frames/s%s\n",
+                                        c->frame_seq, c->width_div, c->slot_mult, c->frame_seq - c->width_t0_seq, util, rate,
+                                        c->width_prev != 0 ? " (trial)" : "");
                 if (c->width_prev != 0) {                    // a trial ends: keep the new setting only if it pays
                     if (rate < 1.03 * c->width_prev_rate) { next_div = c->width_prev; next_mult = c->mult_prev; c->width_settled = true; }
                     c->width_prev = 0;
@@ -1239,7 +1244,12 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                     const uint32_t cand = c->width_div == 1u ? 4u : c->width_div * 2u;
                     const bool can_narrow = cand <= mrt_ctx::kMaxFrameSlots && (uint64_t)c->n_tiles * cand >= 2ull * c->n_waves && c->n_waves >= cand;
                     const bool can_add = in_flight * 2u <= mrt_ctx::kMaxFrameSlots;
-                    if (util < 0.95 && (can_narrow || can_add)) {
+                    // (a window's utilisation scatters by a few per cent around the workload's own -- C3: 0.93 to 0.99 around 0.970,
+                    // depending on how the frames in flight happened to share the chip -- so one low window only asks for a second)
+                    if (util < 0.95 && (can_narrow || can_add) && ++c->width_low_windows < 2u) {
+                        // measure again at the same setting
+                    } else if (util < 0.95 && (can_narrow || can_add)) {
+                        c->width_low_windows = 0;
                         c->width_prev = c->width_div;
                         c->mult_prev = c->slot_mult;
                         c->width_prev_rate = rate;
@@ -1353,8 +1363,8 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], S.stream));
     HIP_TRY(c, hipEventRecord(S.render_done, S.stream));
     if (adaptive) {         // the launch-width controller's sample: cumulative world_hit calls and lane slots after this kernel
-        HIP_TRY(c, hipMemcpyAsync(c->h_stats + 2 * c->last_slot, c->d_counters + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_stats + 2 * c->last_slot + 1, c->d_counters + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
+        // (counters 1 .. 3 in ONE copy: world_hit calls and lane slots of the same instant)
+        HIP_TRY(c, hipMemcpyAsync(c->h_stats + 3 * c->last_slot, c->d_counters + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
         HIP_TRY(c, hipEventRecord(S.stats_ready, S.stream));
         S.stats_seq = c->frame_seq;
         S.stats_pending = true;

@@ -87,7 +87,7 @@ struct mrt_ctx {
         // and its last finalize launch fails, it is not: the next launch on this slot resets it itself.
         bool queue_dirty = false;
         // launch-width controller: the context's cumulative {world_hit calls, lane slots} copied to pinned host memory right
-        // after this slot's render kernel (h_stats[2 slot ..]), the event that says the copy has landed, the frame it was
+        // after this slot's render kernel (h_stats[3 slot ..]: counters 1 .. 3 in one copy), the event that says the copy has landed, the frame it was
         hipEvent_t stats_ready = nullptr;
         uint64_t stats_seq = 0;
         bool stats_pending = false;
@@ -107,13 +107,14 @@ struct mrt_ctx {
                                                     // (C1: 1,450 tiles for 5,120 waves: 2 / 4 / 8 in flight 2,470 / 4,040 / 6,960 Msamples/s)
     uint32_t width_prev = 0, mult_prev = 1;         // what a running trial would return to (width_prev 0 = no trial)
     bool width_settled = false;                     // no further trials for this workload
+    uint32_t width_low_windows = 0;                 // consecutive windows below the utilisation threshold (a trial takes two)
     double width_prev_rate = 0.0;                   // frames / s measured at width_prev
     uint64_t width_valid_from = 0;                  // frame_seq from which samples and timings belong to the current width
     bool width_timing = false;                      // a measurement window is open: since frame width_t0_seq, at width_t0
     uint64_t width_t0_seq = 0;
     std::chrono::steady_clock::time_point width_t0;
     struct LaneStat { uint64_t seq = 0, hits = 0, slots = 0; bool valid = false; } stat_base, stat_last;
-    unsigned long long* h_stats = nullptr;          // pinned, 2 x kMaxFrameSlots
+    unsigned long long* h_stats = nullptr;          // pinned, 3 x kMaxFrameSlots
     hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
     bool inputs_dirty = true;
     uint64_t frame_seq = 0;
