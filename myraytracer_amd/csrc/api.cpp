@@ -1246,7 +1246,8 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                     const bool can_add = in_flight * 2u <= mrt_ctx::kMaxFrameSlots;
                     // (a window's utilisation scatters by a few per cent around the workload's own -- C3: 0.93 to 0.99 around 0.970,
                     // depending on how the frames in flight happened to share the chip -- so one low window only asks for a second)
-                    if (util < 0.95 && (can_narrow || can_add) && ++c->width_low_windows < 2u) {
+                    // (below 0.90 one window is evidence enough: a pixel-starved share reads 0.4 to 0.8)
+                    if (util >= 0.90 && util < 0.95 && (can_narrow || can_add) && ++c->width_low_windows < 2u) {
                         // measure again at the same setting
                     } else if (util < 0.95 && (can_narrow || can_add)) {
                         c->width_low_windows = 0;
