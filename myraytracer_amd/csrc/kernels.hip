@@ -833,7 +833,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                 } else {
                     // Large scenes.  Every owner first FILTERS its own candidates -- does its line touch the record's BOX (the
                     // sweep tested its bounding sphere)? -- in the lane: one record of its masks per trip, its ray in registers,
-                    // the record's box from L1, one box ahead.  (Round 3 wrote the raw candidates to a queue and read them back
+                    // the record's box (from the group's LDS copy of the upper levels) one trip ahead.  (Round 3 wrote the raw candidates to a queue and read them back
                     // in filter rounds: two LDS round trips and a round's fixed costs per candidate more; C5 +7 %.)  The
                     // survivors feed three queues, deepest first:
                     //   inner    ONE stack for every level below the top: (owner, node g), g numbered top-down over the complete

@@ -31,8 +31,8 @@ python scripts/config_rates.py > $O/config_rates.txt 2>&1
   MRT_WARMUP=16 MRT_NOBATCH=1 python scripts/shard_throughput.py stress 1920 1080 4096 5 8 32 0
   MRT_WARMUP=16 MRT_NOBATCH=1 MRT_SLOTS=2 python scripts/shard_throughput.py stress 1920 1080 4096 0 8 6 0     # round 3's schedule: 2 frames in flight on all waves
   MRT_WARMUP=8 python scripts/shard_throughput.py stress 1920 1080 4096 0 8 6 1
-  MRT_WARMUP=24 MRT_NOBATCH=1 python scripts/shard_throughput.py stress 1920 1080 4096 0 4 12 0
-  MRT_WARMUP=24 MRT_NOBATCH=1 python scripts/shard_throughput.py stress 1920 1080 4096 0 2 10 0
+  MRT_WARMUP=32 MRT_NOBATCH=1 python scripts/shard_throughput.py stress 1920 1080 4096 0 4 24 0      # (enough frames for the controller's trials to be over and for a few convoys of frames)
+  MRT_WARMUP=28 MRT_NOBATCH=1 python scripts/shard_throughput.py stress 1920 1080 4096 0 2 16 0
   MRT_WARMUP=8 python scripts/shard_throughput.py cover-glass 3840 2160 1024 0 8 6 0
   MRT_WARMUP=8 python scripts/shard_throughput.py cover-glass 3840 2160 1024 0 8 6 1 ) > $O/shard_throughput.txt 2>&1
 MRT_LIB_OVERRIDE=$PWD/myraytracer_amd/lib/libmyraytracer_amd_stamps.so python scripts/phase_profile.py cover-glass 1920 1080 64 > $O/c3_phase.txt
