@@ -1226,7 +1226,10 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
                 c->width_t0_seq = c->frame_seq;
                 c->width_t0 = now;
             }
-            if (c->width_timing && c->frame_seq >= c->width_t0_seq + 2u * in_flight + 2u && c->stat_base.valid && c->stat_last.valid &&
+            // (... and over at least 20 ms: frames of a fifth of a millisecond -- C1, 1 spp -- filled a window in 2-3 ms of host time,
+            // whose jitter decided 1 trial in 9 the wrong way)
+            if (c->width_timing && c->frame_seq >= c->width_t0_seq + 2u * in_flight + 2u &&
+                std::chrono::duration<double>(now - c->width_t0).count() >= 0.020 && c->stat_base.valid && c->stat_last.valid &&
                 c->stat_last.seq > c->stat_base.seq && c->stat_last.slots > c->stat_base.slots && c->stat_last.hits >= c->stat_base.hits) {
                 const double util = (double)(c->stat_last.hits - c->stat_base.hits) / (double)(c->stat_last.slots - c->stat_base.slots);
                 const double rate = (double)(c->frame_seq - c->width_t0_seq) / std::max(1e-9, std::chrono::duration<double>(now - c->width_t0).count());

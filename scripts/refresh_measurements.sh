@@ -12,11 +12,11 @@ python bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 python bench.py --config c4 --steps 4 --warmup 2 > $O/bench_c4.json 2>/dev/null
 python bench.py --config c5 --steps 4 --warmup 4 > $O/bench_c5.json 2>/dev/null
 python bench.py --config c5 --rng counter --no-cpu-baseline --steps 3 --warmup 2 > $O/bench_c5_counter.json 2>/dev/null
-python bench.py --config c1 --steps 800 --warmup 200 > $O/bench_c1.json 2>/dev/null
+python bench.py --config c1 --steps 800 --warmup 600 > $O/bench_c1.json 2>/dev/null
 python bench.py --config c1 --no-cpu-baseline --frames-per-step 32 --steps 20 --warmup 2 > $O/bench_c1_x32.json 2>/dev/null
 python bench.py --config c2 --steps 80 --warmup 60 > $O/bench_c2.json 2>/dev/null
 python bench.py --config c2 --no-cpu-baseline --frames-per-step 32 --steps 4 --warmup 1 > $O/bench_c2_x32.json 2>/dev/null
-python bench.py --config interactive --no-cpu-baseline --steps 800 --warmup 200 > $O/bench_interactive.json 2>/dev/null
+python bench.py --config interactive --no-cpu-baseline --steps 800 --warmup 600 > $O/bench_interactive.json 2>/dev/null
 python bench.py --config interactive --no-cpu-baseline --frames-per-step 32 --steps 20 --warmup 2 > $O/bench_interactive_x32.json 2>/dev/null
 MRT_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --verify > $O/bench_forced_dist.json 2>/dev/null
 MRT_BENCH_ABI_DEVICES=0,0 MRT_BENCH_BACKEND=gloo python bench.py --gpus 2 --no-cpu-baseline --verify --steps 2 --warmup 1 > $O/rehearsal_gloo_n2.json 2>/dev/null
