@@ -7,7 +7,9 @@ a spill (v_writelane), copy (s_mov) or reuse of those SGPRs in between would rea
 data that has not landed.  This script compiles kernels.hip to ISA, rebuilds the control-flow
 graph of every render_kernel instantiation and verifies that on every path from a hand-issued
 load to the first `s_waitcnt ... lgkmcnt(0)` (ours or hipcc's: either lands all outstanding
-scalar loads) no instruction reads or writes the load's destination SGPRs.  Exit code 0 = verified.
+scalar loads) no instruction reads or writes the load's destination SGPRs.  It also pins two compiler
+accidents found in round 4 (no flat memory instructions; the large-scene walk's queue scheduling on the
+scalar side): see check_kernel.  Exit code 0 = verified.
 
     python scripts/check_isa.py [--flags "<hipcc flags>"]
 """
@@ -98,6 +100,17 @@ def check_kernel(name, lines):
         errors.append(f"{name}: no hand-issued s_load_dwordx16 found (sweep not recognised)")
     if mfma_variant and not any("v_mfma_f32_32x32x16_bf16" in l for l in lines):
         errors.append(f"{name}: matrix-core sweep variant without v_mfma_f32_32x32x16_bf16")
+    # Two compiler accidents of round 4, pinned (DESIGN_HISTORY.md): (1) no flat memory instruction anywhere -- two sources of
+    # one value (LDS / global copies of the boxes) as generic pointers were merged into a flat load of a selected pointer,
+    # which goes down the texture path whatever it reads; (2) large scenes (fourth argument 1 / 2): which queue the walk's
+    # next round takes is decided on the scalar side -- a reference to one of the queue counters had put the counters, and
+    # with them the scheduling, into VGPRs (`v_cmp_lt_u32 vcc, 63, v..` in every round)
+    flat = [instr(k) for k in range(n) if re.match(r"flat_(load|store|atomic)", instr(k))]
+    if flat:
+        errors.append(f"{name}: {len(flat)} flat memory instruction(s), first `{flat[0]}`")
+    large = len(flags) >= 4 and flags[3] in ("1", "2")
+    if large and any(re.match(r"v_cmp_\w+_u32\w*\s+(vcc|s\[\d+:\d+\]),\s*6[34],\s*v\d+", instr(k)) for k in range(n)):
+        errors.append(f"{name}: a queue counter is compared with 63 / 64 on the vector side (the walk's scheduling left the SGPRs)")
     return errors
 
 
