@@ -1381,6 +1381,12 @@ uint32_t large_scene_box_lds_count(uint32_t n_top_padded, uint32_t levels, uint3
     if (n_top_padded <= cap && large_scene_stack_cap(mask_chunks, n_top_padded) >= kMinStack) return n_top_padded;
     return 0u;
 }
+// how many render waves the chip holds at a time for p's scene layout (what a launch width divides)
+uint32_t render_resident_waves(const KParams& p) {
+    uint32_t lay[2];
+    render_lds_layout(p, lay);
+    return p.cus * lay[1] * kWavesPerGroup;
+}
 // the wave's work-stack capacity that makes a large scene's workgroup fit 4 per CU (160 KB / 4 groups, minus the boxes the group
 // shares, / 4 waves); a multiple of 4 entries, so that every wave's LDS starts 16-byte aligned
 uint32_t large_scene_stack_cap(uint32_t mask_chunks, uint32_t box_lds_count) {

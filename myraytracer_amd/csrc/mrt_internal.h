@@ -137,6 +137,7 @@ int render_waves_per_cu(int* out);
 // host only: {LDS bytes of one render workgroup, workgroups per CU} for p's scene layout; the work-stack capacity (entries)
 // of a large scene's wave with `mask_chunks` chunks of candidate masks
 void render_lds_layout(const KParams& p, uint32_t out[2]);
+uint32_t render_resident_waves(const KParams& p);
 uint32_t large_scene_stack_cap(uint32_t mask_chunks, uint32_t box_lds_count);
 // how many leading boxes of the top-down numbering a large scene's workgroup keeps in LDS: the top level (n_top padded records)
 // and the 4 n_top slots of the level below, or the top alone, or none -- the most that leaves the waves their work stacks
