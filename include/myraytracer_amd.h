@@ -33,7 +33,10 @@ extern "C" {
 /* 3: round 4 -- the diagnostic entry points (mrt_debug_*) moved to myraytracer_amd_debug.h; mrt_build_id added; since 2 the
  * library also gained mrt_set_draw_counting and the boxes / frame-batching diagnostics, and mrt_debug_set_hierarchy /
  * mrt_debug_build_hierarchy accept top_target 0 = automatic ("ABI history"). */
-#define MRT_ABI_VERSION 3
+/* 4: round 5 -- MRT_ERR_STALLED and mrt_set_wait_timeout (every blocking host wait has a deadline), mrt_set_schedule_hint /
+ * mrt_get_schedule (the launch schedule a run settled at can be read and pinned); mrt_create no longer touches the process
+ * environment (GPU_MAX_HW_QUEUES is the host's to set: INTEGRATION.md 2a). */
+#define MRT_ABI_VERSION 4
 
 typedef enum {
     MRT_OK = 0,
@@ -44,7 +47,9 @@ typedef enum {
     MRT_ERR_BAD_SCENE = 5,     /* index out of range, non-finite or out-of-range geometry */
     MRT_ERR_TOO_SMALL = 6,     /* caller buffer too small */
     MRT_ERR_STATE = 7,         /* call not allowed in this state (e.g. reshard after first frame) */
-    MRT_ERR_IO = 8
+    MRT_ERR_IO = 8,
+    MRT_ERR_STALLED = 9        /* a wait for the GPU passed its deadline (mrt_set_wait_timeout); mrt_last_error names the wait.
+                                  The context stays failed: destroy it (mrt_destroy does not wait for a stalled context) */
 } mrt_status;
 
 /* ---- raytracer::Args, lib.rs:18-37; flags of native-runner/src/main.rs:20-31 ---- */
@@ -151,6 +156,13 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out);
 /* Drop of State's wgpu handles */
 void mrt_destroy(mrt_ctx* ctx);
 
+/* Deadline, in seconds, of every wait for the GPU inside this library (the back-pressure of mrt_redraw, mrt_sync, read-backs,
+ * re-allocations, mrt_destroy): a wait that lasts longer fails with MRT_ERR_STALLED and names itself ("back-pressure of slot 3,
+ * frame 17, 8 frames in flight") instead of hanging -- the reference's frame loop would block in wgpu's present forever
+ * (lib.rs:270).  Default 120 s (or the environment's MRT_WAIT_TIMEOUT_S at mrt_create); 0 = no deadline.  Must exceed the
+ * longest single frame the caller renders. */
+int mrt_set_wait_timeout(mrt_ctx* ctx, double seconds);
+
 /* Tile sharding for multi-GPU (no reference counterpart): this ctx renders the 8-row
  * bands b with b % world == rank.  Must be called before the first redraw.  Seeds are
  * keyed by global pixel index, so any sharding yields the same image. */
@@ -195,9 +207,27 @@ int mrt_read_seeds(mrt_ctx* ctx, uint32_t* out, size_t cap_u32);    /* this shar
  * samples_per_frame spp into framebuffers.target blended with .secondary, swap,
  * sample_count += 1, framebuffer_weight = min(max_w, n/(n+1)), new rng_shuffle, Locals
  * update.  Asynchronous on the ctx's stream, like a swap chain: consecutive frames overlap on the GPU (2 in flight; up to 8 for a
- * shard with too few pixels to fill the chip), and the call returns at once unless that many frames are already queued -- then
- * it waits for the oldest one's render kernel.  The next call's blend is ordered behind this one's on the ctx's stream. */
+ * shard with too few pixels to fill the chip, see mrt_get_schedule), and the call returns at once unless that many frames
+ * are already queued.
+ * BACK-PRESSURE: in that case the call blocks the HOST (polling, with the deadline of mrt_set_wait_timeout) until the render
+ * kernel of the oldest frame in flight has completed.  That kernel runs on a side stream of the library and waits only for
+ * work queued by EARLIER calls (its slot's previous blend on the ctx's stream, the scene / seed uploads), never for anything
+ * the caller submits later -- but a caller that gates the ctx's stream on an event it records only AFTER further mrt_redraw
+ * calls can deadlock itself here, and the call must not be made while the ctx's stream is being captured into a graph.
+ * The next call's blend is ordered behind this one's on the ctx's stream. */
 int mrt_redraw(mrt_ctx* ctx);
+/* The launch schedule (no reference counterpart: lib.rs:241-307 has one frame after the other).  A frame's render kernel runs
+ * on 1 / div of the persistent waves the chip holds and max(2, div) x mult frames are in flight; the library measures its way
+ * to a setting over the first frames of a workload.  mrt_get_schedule: out[0] = div, out[1] = mult, out[2] = 1
+ * once the setting is final for the current workload (or pinned), out[3] = frames in flight, out[4] = the share the most recent
+ * launch really got (1 / out[4]: never narrower than the frames the caller really keeps in flight), out[5] = frames that can run
+ * side by side in this process (hardware queues: GPU_MAX_HW_QUEUES).
+ * mrt_set_schedule_hint pins (div, mult) -- e.g. what an earlier run of the same workload settled at, or rank 0's setting on
+ * every rank of a multi-GPU run -- so that no trial runs and two runs schedule alike; (0, 0) returns to the measured
+ * setting.  div 1..8, mult 1..4, max(2, div) x mult <= 8.  Takes effect at the next redraw (a change waits for the frames
+ * under way); the images are the same whatever the schedule. */
+int mrt_get_schedule(mrt_ctx* ctx, uint32_t out[6]);
+int mrt_set_schedule_hint(mrt_ctx* ctx, uint32_t div, uint32_t mult);
 /* `frames` x mrt_redraw: the same images.  Frames are independent until their blend, so when the (shard of the) image has
  * fewer than about two pixels per GPU lane -- a pixel is one sequential chain of samples, lib.rs:299-306's remedy for that is
  * more frames -- up to 32 consecutive frames of the stream mode share one render launch (also when a frame is very short).

@@ -120,9 +120,23 @@ int mrt_debug_lds_layout(uint32_t n_members, uint32_t n_nodes, uint32_t levels, 
 /* Diagnostic / tuning: how many frames may be in flight (each on a side stream of its own; 1..8), 0 = automatic: 2, more for
  * pixel-starved shards.  A change waits for the frames under way.  The images are the same. */
 int mrt_debug_set_frames_in_flight(mrt_ctx* ctx, int slots);
+/* Host only, no GPU needed: the launch-width controller's policy (csrc/width_policy.h) on synthetic input, for its CPU unit
+ * tests.  workload[6] = {n_tiles, n_waves, max_slots, spp, n_members, counter-RNG?}; state[7] in / out = {div, mult, prev_div,
+ * prev_mult, low_windows, settled, prev_rate as the bits of an f32}.  op 0: what is known up front (state out only);
+ * op 1: one measurement window has closed with lane utilisation `util` and `rate` frames / s; op 2: state[0] out = the share a
+ * launch gets under setting state[0] when `util` (as an integer) earlier frames are still queued or running. */
+int mrt_debug_width_policy(int op, const uint32_t workload[6], uint32_t state[7], double util, double rate);
+/* Diagnostic: how many of `streams` (2..8) side streams of this context really run side by side in this process -- identical
+ * short clock-bounded kernels, one per stream, timed against one alone: *out = streams x t_one / t_all (hardware queues are
+ * shared round-robin: HIP's default of 4 per process gives about 4).  What caps the frames in flight (mrt_get_schedule). */
+int mrt_debug_stream_concurrency(mrt_ctx* ctx, uint32_t streams, float* out);
 /* Diagnostic: per-wave log {t_start, t_end (100 MHz ticks), loop trips, bounces}, 4 u64 per 8x8
  * persistent wave, written only by the -DMRT_STAMPS build.  out == NULL allocates the log. */
 int mrt_debug_wave_log(mrt_ctx* ctx, uint64_t* out, size_t cap_waves, size_t* n_waves);
+/* The same for the frame `back` (0..31) redraws before the most recent one: the log is a ring over the last 32 frames, so that
+ * the frames in flight of a narrow schedule can be laid side by side (scripts/shard_occupancy.py).  Entries of waves a launch
+ * did not have are zero. */
+int mrt_debug_wave_log_frame(mrt_ctx* ctx, uint32_t back, uint64_t* out, size_t cap_waves, size_t* n_waves);
 /* Host wall time (ms) the most recent mrt_set_world* call spent building and uploading the bounding-sphere
  * hierarchy (a one-off per scene, outside the per-frame metric). */
 int mrt_debug_last_set_world_ms(mrt_ctx* ctx, float* ms);

@@ -8,11 +8,11 @@ from . import _lib
 from .api import (DIELECTRIC, LAMBERTIAN, METAL, SPHERE_DTYPE, Args, Camera, Dielectric, Lambertian, Metal,
                   MrtError, Sphere, State, World, camera_derive, frame_shuffle, frame_weight, pack_world,
                   gather, load_scene, pixel_seed, save_scene, scene_cover, scene_default, scene_stress, shard_global_row,
-                  shard_local_rows, unshard_rows, write_image)
+                  shard_local_rows, unshard_rows, width_policy, write_image)
 
 _lib.load()
 
 __all__ = ["Args", "Camera", "Dielectric", "Lambertian", "Metal", "Sphere", "State", "World", "MrtError",
            "LAMBERTIAN", "METAL", "DIELECTRIC", "SPHERE_DTYPE", "pack_world", "camera_derive", "frame_weight",
            "frame_shuffle", "pixel_seed", "scene_default", "scene_cover", "scene_stress", "save_scene", "load_scene", "write_image",
-           "gather", "shard_global_row", "shard_local_rows", "unshard_rows"]
+           "gather", "shard_global_row", "shard_local_rows", "unshard_rows", "width_policy"]

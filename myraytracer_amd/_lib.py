@@ -12,6 +12,7 @@ import sys
 # Up to 8 frames of a pixel-starved shard run at a time, each on a HIP stream of its own (api.cpp, redraw_frames); they only
 # run side by side on hardware queues of their own, and HIP's default is 4 per process.  Read by the runtime when it
 # initialises -- set here, at import, before anything (torch included) has made a HIP call.  Never overrides the caller's value.
+# (The C library itself never touches the environment: it measures what it got and holds its schedule to that.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -31,6 +32,7 @@ EXPORTS = [
     "mrt_scene_stress", "mrt_scene_save", "mrt_scene_load", "mrt_write_pfm", "mrt_write_ppm",
     "mrt_srgb8", "mrt_write_png", "mrt_gather", "mrt_gather_rccl", "mrt_gathered_device_ptr", "mrt_read_gathered",
     "mrt_shard_global_row", "mrt_shard_local_rows", "mrt_unshard_rows", "mrt_debug_last_set_world_ms", "mrt_debug_world_hit", "mrt_debug_set_frame_batching", "mrt_debug_set_gather_per_band", "mrt_debug_arith", "mrt_debug_arith_pairs", "mrt_debug_set_boxes", "mrt_debug_build_boxes", "mrt_set_draw_counting", "mrt_debug_last_launch", "mrt_debug_set_frames_in_flight", "mrt_debug_lds_layout", "mrt_debug_build_boxes_top_down",
+    "mrt_set_wait_timeout", "mrt_get_schedule", "mrt_set_schedule_hint", "mrt_debug_width_policy", "mrt_debug_stream_concurrency", "mrt_debug_wave_log_frame",
 ]
 
 
@@ -257,6 +259,12 @@ def load():
         "mrt_debug_set_frames_in_flight": (i32, [vp, i32]),
         "mrt_debug_lds_layout": (i32, [u32, u32, u32, u32, P(u32)]),
         "mrt_debug_build_boxes_top_down": (i32, [vp, sz, u32, u32, i32, vp, sz, vp]),
+        "mrt_set_wait_timeout": (i32, [vp, C.c_double]),
+        "mrt_get_schedule": (i32, [vp, P(u32)]),
+        "mrt_set_schedule_hint": (i32, [vp, u32, u32]),
+        "mrt_debug_width_policy": (i32, [i32, P(u32), P(u32), C.c_double, C.c_double]),
+        "mrt_debug_stream_concurrency": (i32, [vp, u32, P(f32)]),
+        "mrt_debug_wave_log_frame": (i32, [vp, u32, vp, sz, P(sz)]),
     }
     assert sorted(sig) == sorted(EXPORTS)
     for name, (res, args) in sig.items():

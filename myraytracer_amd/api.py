@@ -219,6 +219,24 @@ def write_image(path: str, rgba: np.ndarray):
         raise MrtError(st, "write_image", path)
 
 
+def width_policy(op: int, workload: Sequence[int], state: Sequence[int], util: float = 0.0, rate: float = 0.0):
+    """The launch-width controller's policy (csrc/width_policy.h) on synthetic input; host only.  workload = (n_tiles, n_waves,
+    max_slots, spp, n_members, counter); state = (div, mult, prev_div, prev_mult, low_windows, settled, prev_rate).  Returns
+    the new state (op 0: start, op 1: a window closed) or the launch share (op 2, util = frames still running)."""
+    import struct
+    L = _lib.load()
+    w = (C.c_uint32 * 6)(*[int(x) for x in workload])
+    st = list(state) if state is not None else [0, 1, 0, 1, 0, 0, 0.0]
+    bits = struct.unpack("<I", struct.pack("<f", float(st[6])))[0]
+    sv = (C.c_uint32 * 7)(*[int(x) for x in st[:6]], bits)
+    rc = L.mrt_debug_width_policy(op, w, sv, float(util), float(rate))
+    if rc:
+        raise MrtError(rc, "mrt_debug_width_policy")
+    if op == 2:
+        return int(sv[0])
+    return [int(sv[i]) for i in range(6)] + [struct.unpack("<f", struct.pack("<I", sv[6]))[0]]
+
+
 # ------------------------------------------------------------------ State
 
 class State:
@@ -401,6 +419,26 @@ class State:
         out = (C.c_uint32 * 2)()
         self._check(self._L.mrt_debug_last_launch(self._ctx, out), "mrt_debug_last_launch")
         return int(out[0]), (None if out[1] == 0xFFFFFFFF else int(out[1]))
+
+    def set_wait_timeout(self, seconds: float):
+        """Deadline of every wait for the GPU inside the library (0 = none): a longer wait raises MrtError(MRT_ERR_STALLED)."""
+        self._check(self._L.mrt_set_wait_timeout(self._ctx, float(seconds)), "mrt_set_wait_timeout")
+
+    def get_schedule(self) -> dict:
+        """The launch schedule: a frame runs on 1 / div of the persistent waves, max(2, div) x mult frames are in flight."""
+        out = (C.c_uint32 * 6)()
+        self._check(self._L.mrt_get_schedule(self._ctx, out), "mrt_get_schedule")
+        return {"div": int(out[0]), "mult": int(out[1]), "settled": bool(out[2]), "frames_in_flight": int(out[3]),
+                "last_launch_div": int(out[4]), "max_concurrent_frames": int(out[5])}
+
+    def set_schedule_hint(self, div: int, mult: int = 1):
+        """Pin the launch schedule (what an earlier run settled at); (0, 0) = measure again.  The images do not change."""
+        self._check(self._L.mrt_set_schedule_hint(self._ctx, div, mult), "mrt_set_schedule_hint")
+
+    def debug_stream_concurrency(self, streams: int = 8) -> float:
+        out = C.c_float()
+        self._check(self._L.mrt_debug_stream_concurrency(self._ctx, streams, C.byref(out)), "mrt_debug_stream_concurrency")
+        return float(out.value)
 
     def debug_set_frames_in_flight(self, slots: int):
         """How many frames may be in flight, each on a side stream of its own (1..8; 0 = automatic)."""

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mrt_internal.h"
@@ -117,7 +118,7 @@ int alloc_frame_buffers(mrt_ctx* c) {
         S.pix_acc_layers = 1;
     }
     c->frame_slots = 2;
-    c->width_div = 0;
+    c->width.div = 0;
     c->inputs_dirty = true;
     // as many persistent single-wave workgroups as the chip holds
     {
@@ -621,14 +622,55 @@ hipError_t create_slot_streams(mrt_ctx::FrameSlot& S) {
     return e;
 }
 
-// wait for everything this context has in flight (caller's stream and the side streams)
-hipError_t sync_all(mrt_ctx* c) {
-    hipError_t e = hipSuccess, r;
-    for (auto& S : c->slot)
-        if (S.stream && (r = hipStreamSynchronize(S.stream)) != hipSuccess) e = r;
-    if (c->stream && (r = hipStreamSynchronize(c->stream)) != hipSuccess) e = r;
-    return e;
+}  // namespace
+
+namespace mrt {
+
+// Bounded host waits.  Every wait for the GPU in this library goes through these: poll (spin briefly, then sleep in growing
+// steps up to 200 us -- a frame is 0.2 ms at its shortest) until the event / stream is complete or the context's deadline has
+// passed; then fail with MRT_ERR_STALLED and a message that names the wait, so that a stall is a loud status and never a silent
+// hang (round 4's parity campaign lost a 420-s run to one: DESIGN_HISTORY.md, round 5).
+template <typename Query>
+static int bounded_wait(mrt_ctx* c, Query query, const char* what) {
+    if (c->stalled) return fail(c, MRT_ERR_STALLED, "%s: the context has stalled before (destroy it)", what);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = query();
+        if (q == hipSuccess) return MRT_OK;
+        if (q != hipErrorNotReady) return fail(c, MRT_ERR_HIP, "%s: %s", what, hipGetErrorString(q));
+        (void)hipGetLastError();                                        // (hipErrorNotReady is not an error)
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (c->wait_timeout_s > 0.0 && waited > c->wait_timeout_s) {
+            c->stalled = true;
+            return fail(c, MRT_ERR_STALLED, "stalled in %s: not complete after %.1f s (mrt_set_wait_timeout)", what, waited);
+        }
+        if (waited < 50e-6) continue;                                   // spin
+        std::this_thread::sleep_for(std::chrono::microseconds(waited < 2e-3 ? 20 : waited < 50e-3 ? 100 : 200));
+    }
 }
+int wait_event(mrt_ctx* c, hipEvent_t ev, const char* what) { return bounded_wait(c, [&]() { return hipEventQuery(ev); }, what); }
+int wait_stream(mrt_ctx* c, hipStream_t s, const char* what) { return bounded_wait(c, [&]() { return hipStreamQuery(s); }, what); }
+// everything this context has in flight (the side streams, then the caller's stream)
+int wait_all(mrt_ctx* c, const char* what) {
+    char buf[160];
+    for (uint32_t i = 0; i < mrt_ctx::kMaxFrameSlots; i++) {
+        mrt_ctx::FrameSlot& S = c->slot[i];
+        if (!S.stream) continue;
+        std::snprintf(buf, sizeof buf, "%s (side stream of slot %u, last frame %llu, %u frames in flight)", what, i,
+                      (unsigned long long)S.render_seq, c->frame_slots);
+        MRT_TRY(wait_stream(c, S.stream, buf));
+        S.render_pending = false;
+    }
+    if (c->stream) {
+        std::snprintf(buf, sizeof buf, "%s (the context's stream, frame %llu)", what, (unsigned long long)c->frame_seq);
+        MRT_TRY(wait_stream(c, c->stream, buf));
+    }
+    return MRT_OK;
+}
+
+}  // namespace mrt
+
+namespace {
 
 }  // namespace
 
@@ -649,6 +691,7 @@ const char* mrt_status_string(int s) {
         case MRT_ERR_TOO_SMALL: return "buffer too small";
         case MRT_ERR_STATE: return "call not allowed in this state";
         case MRT_ERR_IO: return "i/o error";
+        case MRT_ERR_STALLED: return "a wait for the GPU passed its deadline";
         default: return "unknown status";
     }
 }
@@ -783,13 +826,11 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
     mrt_args_resolve_size(&a);
     if (a.width > (1u << 20) || a.height > (1u << 20))
         return fail(nullptr, MRT_ERR_INVALID_ARG, "mrt_create: image %ux%u too large", a.width, a.height);
-    // The frames in flight of a pixel-starved shard (redraw_frames: up to 8, each on a side stream of its own) must really run
-    // side by side, i.e. on hardware queues of their own.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES (default
-    // 4) hardware queues and kernels of streams that share one serialise (measured, round 4: 8 frames in flight ran 2.7 at a
-    // time; with 16 queues all 8: C5's 1/8 share 1,050 -> 2,370 Msamples/s).  The runtime reads the variable when it
-    // initialises, so this only helps if no HIP call has been made in the process yet; a host that initialises HIP first sets
-    // it itself (bench.py and the Python package do).  Never overrides the caller's value.
-    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    // (The frames in flight of a pixel-starved shard -- up to 8, each on a side stream of its own -- only run side by side on
+    // hardware queues of their own, and HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES of them, 4 by default.  That
+    // variable is the HOST's to set, before its first HIP call: INTEGRATION.md 2a; the Python package and bench.py do.  This
+    // library does not touch the environment: it measures how many of its streams really run at a time when it first wants
+    // more than two frames in flight -- probe_stream_concurrency -- and holds the schedule to that.)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, MRT_ERR_NO_DEVICE, "mrt_create: no HIP device (this backend has no CPU fallback)");
@@ -804,6 +845,11 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
     mrt_ctx* c = new (std::nothrow) mrt_ctx();
     if (!c) return fail(nullptr, MRT_ERR_INVALID_ARG, "mrt_create: out of host memory");
     c->device = device; c->args = a; c->seed = seed;
+    if (const char* t = std::getenv("MRT_WAIT_TIMEOUT_S")) {
+        char* end = nullptr;
+        const double v = std::strtod(t, &end);
+        if (end != t && v >= 0.0 && std::isfinite(v)) c->wait_timeout_s = v;
+    }
     c->cam_raw.mode = 0;
     reset_locals(c);
     auto bail = [&](int st) { g_err = c->err; mrt_destroy(c); return st; };
@@ -828,7 +874,12 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
 void mrt_destroy(mrt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)sync_all(c);
+    // A context that has stalled (MRT_ERR_STALLED) may hold work that never finishes: hipFree, hipStreamDestroy and
+    // hipEventDestroy all wait for it.  Its device resources are then left to the process' exit rather than waited for.
+    if (mrt::wait_all(c, "mrt_destroy") != MRT_OK || c->stalled) {
+        delete c;
+        return;
+    }
     free_frame_buffers(c);
     for (auto& S : c->slot) {
         if (S.render_done) (void)hipEventDestroy(S.render_done);
@@ -858,7 +909,7 @@ int mrt_set_shard(mrt_ctx* c, uint32_t rank, uint32_t world) {
     if (world == 0 || rank >= world) return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_shard: rank %u of %u", rank, world);
     if (c->frames_done != 0) return fail(c, MRT_ERR_STATE, "mrt_set_shard: frames already rendered; call mrt_reset first");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     c->shard_rank = rank; c->shard_world = world;
     return alloc_frame_buffers(c);
 }
@@ -866,7 +917,7 @@ int mrt_set_shard(mrt_ctx* c, uint32_t rank, uint32_t world) {
 int mrt_set_stream(mrt_ctx* c, void* s) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     c->stream = s ? (hipStream_t)s : c->own_stream;
     c->inputs_dirty = true;
     return MRT_OK;
@@ -912,7 +963,7 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
             return fail(c, MRT_ERR_BAD_SCENE, "sphere %lld: material index %d out of range for type %d", (long long)i, mi, ty);
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     free_world(c);
 
     // exact-test records, in the reference's sphere order
@@ -996,7 +1047,7 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
     HIP_TRY(c, upload((void**)&c->d_f32, f32, n_f32 * sizeof(float)));
     HIP_TRY(c, upload((void**)&c->d_i32, i32, n_i32 * sizeof(int32_t)));
     for (auto& S : c->slot) S.cost_valid = false;
-    c->width_div = 0;                   // (the launch-width controller starts over with the new workload)
+    c->width.div = 0;                   // (the launch-width controller starts over with the new workload)
     c->inputs_dirty = true;
     c->world = *w;
     c->n_spheres = (uint32_t)n;
@@ -1039,7 +1090,7 @@ int mrt_set_camera(mrt_ctx* c, const mrt_camera* cam) {
             return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_camera: |lookfrom| or the lens radius exceeds 1e7");
     c->cam_raw = raw;
     for (auto& S : c->slot) S.cost_valid = false;
-    c->width_div = 0;                   // (the launch-width controller starts over with the new workload)
+    c->width.div = 0;                   // (the launch-width controller starts over with the new workload)
     return MRT_OK;
 }
 
@@ -1067,7 +1118,7 @@ static int copy_rows(mrt_ctx* c, void* device_base, void* host_full, size_t texe
         if (to_device) HIP_TRY(c, hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, c->stream));
         else HIP_TRY(c, hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
     return MRT_OK;
 }
 
@@ -1075,7 +1126,7 @@ int mrt_set_seeds(mrt_ctx* c, const uint32_t* seeds, size_t n_u32) {
     if (!c || !seeds) return MRT_ERR_INVALID_ARG;
     if (n_u32 != (size_t)c->args.width * c->args.height * 4) return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_seeds: expected W*H*4 u32");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     c->inputs_dirty = true;
     return copy_rows(c, c->d_seeds, const_cast<uint32_t*>(seeds), 16, true);
 }
@@ -1086,7 +1137,7 @@ int mrt_read_seeds(mrt_ctx* c, uint32_t* out, size_t cap) {
     if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_read_seeds: need %zu u32", n);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(out, c->d_seeds, n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
     return MRT_OK;
 }
 
@@ -1146,6 +1197,183 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.top_mfma = c->d_top_mfma; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.shade = c->d_shade; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
 }
 
+// How many of `k` side streams of this process really run at a time: one clock-bounded single-wave kernel per stream (0.4 ms
+// each; launch_hold) against one alone, on the host's clock.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware
+// queues (4 unless the host set the variable before its first HIP call) and kernels of streams that share one serialise: round 4
+// measured 8 frames in flight running 2.7 at a time on the default, all 8 on 16 queues (C5's 1/8 share 1,050 -> 2,370
+// Msamples/s).  Called once per context, with nothing in flight, when the schedule first asks for more than two frames.
+static int probe_stream_concurrency(mrt_ctx* c, uint32_t k, float* out) {
+    if (k < 2u) k = 2u;
+    if (k > mrt_ctx::kMaxFrameSlots) k = mrt_ctx::kMaxFrameSlots;
+    for (uint32_t i = 0; i < k; i++) HIP_TRY(c, create_slot_streams(c->slot[i]));
+    MRT_TRY(mrt::wait_all(c, "probe_stream_concurrency"));
+    const unsigned long long ticks = 40000ull;              // 0.4 ms of the 100 MHz clock
+    auto timed = [&](uint32_t n, double* seconds) -> int {
+        // (a first launch per stream outside the clock: code object load, queue creation)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t i = 0; i < n; i++) {
+            const int e = mrt::launch_hold(ticks, 1u << 14, nullptr, c->slot[i].stream);
+            if (e) return fail(c, MRT_ERR_HIP, "probe_stream_concurrency: launch failed: %s", hipGetErrorString((hipError_t)e));
+        }
+        for (uint32_t i = 0; i < n; i++) MRT_TRY(mrt::wait_stream(c, c->slot[i].stream, "probe_stream_concurrency"));
+        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return MRT_OK;
+    };
+    double warm = 0.0, one = 0.0, all = 0.0;
+    MRT_TRY(timed(k, &warm));
+    MRT_TRY(timed(1, &one));
+    MRT_TRY(timed(k, &all));
+    *out = (float)((double)k * one / std::max(all, 1e-9));
+    return MRT_OK;
+}
+
+// The most frames in flight this process can really run side by side: kMaxFrameSlots where the probe says so, else the largest
+// power of two it supports (>= 2), with ONE line of warning behind mrt_last_error(NULL).
+static int probe_max_slots(mrt_ctx* c) {
+    if (c->slots_probed) return MRT_OK;
+    float conc = 0.0f;
+    MRT_TRY(probe_stream_concurrency(c, mrt_ctx::kMaxFrameSlots, &conc));
+    c->slots_probed = true;
+    uint32_t cap = mrt_ctx::kMaxFrameSlots;
+    while (cap > 2u && conc < 0.8f * (float)cap) cap /= 2u;
+    c->max_slots = cap;
+    if (cap < mrt_ctx::kMaxFrameSlots) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "myraytracer_amd: only %.1f of %u side streams run at a time in this process: at most %u frames in flight "
+                      "(set GPU_MAX_HW_QUEUES=16 before the process' first HIP call: INTEGRATION.md 2a)", conc, mrt_ctx::kMaxFrameSlots, cap);
+        g_err = buf;
+        static const bool trace = std::getenv("MRT_TRACE_WIDTH") != nullptr;
+        if (trace) std::fprintf(stderr, "%s\n", buf);
+    }
+    return MRT_OK;
+}
+
+static mrt::WidthWorkload width_workload(const mrt_ctx* c, bool counter) {
+    mrt::WidthWorkload w;
+    w.n_tiles = c->n_tiles; w.n_waves = c->n_waves; w.max_slots = c->max_slots;
+    w.spp = c->locals.samples_per_frame; w.n_members = c->n_members; w.counter = counter ? 1u : 0u;
+    return w;
+}
+
+// a new setting: the frames of the old one drain first, then samples and timings count again
+static void width_restart_measurement(mrt_ctx* c) {
+    c->width_timing = false;
+    c->width_valid_from = c->frame_seq + mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots);
+    c->stat_base.valid = c->stat_last.valid = false;
+}
+
+// The launch-width controller's bookkeeping for the frame about to be launched (adaptive launches only: one frame per launch,
+// no diagnostic override): the setting for a new workload, the back-pressure, the lane-utilisation samples that have landed,
+// the measurement windows and -- through width_policy.h -- the trials.  *want = frames in flight, *frames_running = earlier
+// frames whose render kernels are still queued or running.
+static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* frames_running) {
+    static const bool trace = std::getenv("MRT_TRACE_WIDTH") != nullptr;      // diagnostics: every decision, on stderr
+    mrt::WidthWorkload w = width_workload(c, counter);
+    if (c->width.div == 0) {
+        if (c->hint_div != 0) {                  // the caller's setting (mrt_set_schedule_hint)
+            c->width = mrt::WidthState();
+            c->width.div = c->hint_div; c->width.mult = c->hint_mult; c->width.settled = 1u;
+        } else {
+            mrt::width_policy_start(c->width, w);
+            // a setting this context has already settled at for the same workload returns without trials
+            for (const auto& m : c->width_memo)
+                if (m.n_tiles == w.n_tiles && m.spp == w.spp && m.large == (w.n_members > 1024u ? 1u : 0u) && m.counter == w.counter &&
+                    m.n_spheres == c->n_spheres) { c->width.div = m.div; c->width.mult = m.mult; c->width.settled = 1u; }
+        }
+        width_restart_measurement(c);
+    }
+    // The host may not run further ahead than the frames in flight: before a slot is used again, its previous frame's
+    // render kernel has completed (a swap-chain's back-pressure; the GPU still holds a full set of frames, queued or
+    // running).  It bounds the queued work and is what lets the samples below arrive while they can still matter -- a
+    // caller that issues its redraws in one burst would otherwise see none of them before its last call.
+    {
+        const uint32_t own = (uint32_t)(c->frame_seq % c->frame_slots);
+        mrt_ctx::FrameSlot& Own = c->slot[own];
+        if (Own.stats_pending) {
+            char what[160];
+            std::snprintf(what, sizeof what, "mrt_redraw: back-pressure of slot %u (render kernel of frame %llu, next frame %llu, %u frames in flight)",
+                          own, (unsigned long long)Own.stats_seq, (unsigned long long)c->frame_seq, c->frame_slots);
+            MRT_TRY(mrt::wait_event(c, Own.stats_ready, what));
+        }
+    }
+    // lane-utilisation samples that have landed (an event that is not ready yet is looked at next time), and the frames still
+    // queued or running
+    uint32_t running = 0;
+    for (uint32_t i = 0; i < c->frame_slots; i++) {
+        mrt_ctx::FrameSlot& T = c->slot[i];
+        if (T.render_pending) {
+            if (hipEventQuery(T.render_done) == hipSuccess) T.render_pending = false; else running++;
+        }
+        if (!T.stats_pending || hipEventQuery(T.stats_ready) != hipSuccess) continue;
+        T.stats_pending = false;
+        if (T.stats_seq < c->width_valid_from) continue;
+        mrt_ctx::LaneStat st{T.stats_seq, c->h_stats[3 * i], c->h_stats[3 * i + 2], true};
+        if (!c->stat_base.valid || st.seq < c->stat_base.seq) c->stat_base = st;
+        if (!c->stat_last.valid || st.seq > c->stat_last.seq) c->stat_last = st;
+    }
+    (void)hipGetLastError();        // (hipEventQuery's hipErrorNotReady is not an error)
+    *frames_running = running;
+    // A measurement window: from the first frame launched at the current setting with the pipeline full, over
+    // 2 x (frames in flight) + 2 frames -- their lane utilisation (the samples above) and, the calls being paced by
+    // the completions (the back-pressure above), their rate on the host's clock -- and over at least 20 ms: frames of a
+    // fifth of a millisecond (C1, 1 spp) filled a window in 2-3 ms of host time, whose jitter decided 1 trial in 9 the wrong way.
+    const uint32_t in_flight = std::max(2u, c->width.div) * c->width.mult;
+    const auto now = std::chrono::steady_clock::now();
+    if (!c->width.settled && !c->width_timing && c->frame_seq >= c->width_valid_from) {
+        c->width_timing = true;
+        c->width_t0_seq = c->frame_seq;
+        c->width_t0 = now;
+    }
+    if (c->width_timing && c->frame_seq >= c->width_t0_seq + 2u * in_flight + 2u &&
+        std::chrono::duration<double>(now - c->width_t0).count() >= 0.020 && c->stat_base.valid && c->stat_last.valid &&
+        c->stat_last.seq > c->stat_base.seq && c->stat_last.slots > c->stat_base.slots && c->stat_last.hits >= c->stat_base.hits) {
+        mrt::WidthWindow m;
+        m.util = (double)(c->stat_last.hits - c->stat_base.hits) / (double)(c->stat_last.slots - c->stat_base.slots);
+        m.rate = (double)(c->frame_seq - c->width_t0_seq) / std::max(1e-9, std::chrono::duration<double>(now - c->width_t0).count());
+        if (trace) std::fprintf(stderr, "mrt width: frame %llu: div %u x %u, window %llu frames, utilisation %.4f, %.2f frames/s%s\n",
+                                (unsigned long long)c->frame_seq, c->width.div, c->width.mult, (unsigned long long)(c->frame_seq - c->width_t0_seq),
+                                m.util, m.rate, c->width.prev_div != 0 ? " (trial)" : "");
+        mrt::width_policy_step(c->width, w, m);
+        if (c->width.settled) {
+            if (trace) std::fprintf(stderr, "mrt width: settled at div %u x %u\n", c->width.div, c->width.mult);
+            c->width_memo.push_back({w.n_tiles, w.spp, w.n_members > 1024u ? 1u : 0u, w.counter, c->n_spheres, c->width.div, c->width.mult});
+        }
+        width_restart_measurement(c);
+    }
+    // more than two frames in flight only where they really run side by side (measured once, when a setting first asks for them)
+    if (mrt::width_frames_in_flight(c->width.div, c->width.mult, mrt_ctx::kMaxFrameSlots) > 2u && !c->slots_probed) {
+        MRT_TRY(probe_max_slots(c));
+        if (c->max_slots < mrt_ctx::kMaxFrameSlots && c->hint_div == 0) {       // start over within what the process can do
+            w.max_slots = c->max_slots;
+            mrt::width_policy_start(c->width, w);
+            width_restart_measurement(c);
+        }
+        *frames_running = 0;            // (the probe waited for everything)
+    }
+    *want = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots);
+    return MRT_OK;
+}
+
+// `want` frame slots in use from the next frame on: a change waits for the frames under way
+static int set_frame_slots(mrt_ctx* c, uint32_t want) {
+    if (want == c->frame_slots) return MRT_OK;
+    MRT_TRY(mrt::wait_all(c, "mrt_redraw: change of the frames in flight"));
+    c->frame_slots = want;
+    // the further slots' streams and colour sums now, in one go: allocated on first use each would wait for the frames in flight
+    for (uint32_t i = 0; i < want; i++) {
+        mrt_ctx::FrameSlot& T = c->slot[i];
+        HIP_TRY(c, create_slot_streams(T));
+        T.stats_pending = false;
+        T.render_pending = false;
+        if (T.pix_acc_layers != 0) continue;
+        const size_t nt = local_texels(c) ? local_texels(c) : 1;
+        HIP_TRY(c, hipMalloc(&T.d_pix_acc, nt * 16));
+        HIP_TRY(c, hipMemsetAsync(T.d_pix_acc, 0, nt * 16, c->stream));
+        T.pix_acc_layers = 1;
+    }
+    return MRT_OK;
+}
+
 extern "C" {
 
 // State::redraw, lib.rs:241-307 (raytrace pass + swap + weight/shuffle update; the present
@@ -1165,126 +1393,17 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
     p.seeds = c->d_seeds;
     p.counters = c->d_counters;
     p.count_draws = c->count_draws ? 1u : 0u;
-    p.wave_log = c->d_wave_log;
+    p.wave_log = nullptr;            // (stamps builds: this frame's part of the log ring, below)
     p.tiles_x = c->tiles_x; p.n_tiles = c->n_tiles;
     p.pilot_spp = c->pilot_spp;
-    // Launch width and frames in flight (mrt_ctx::width_div): a change waits for the frames under way.
+    // Launch width and frames in flight (the controller: schedule_frame below); a change waits for the frames under way.
     const bool adaptive = batch == 1 && c->waves_per_cu_override == 0 && c->frame_slots_override == 0 && c->n_tiles != 0 &&
                           c->locals.samples_per_frame != 0u;
+    uint32_t frames_running = 0;
     {
         uint32_t want = c->frame_slots_override > 0 ? (uint32_t)c->frame_slots_override : 2u;
-        if (adaptive) {
-            if (c->width_div == 0) {
-                // what is known up front.  A pixel-starved launch of long chains (fewer than two pixels per lane the chip holds,
-                // one sequential chain of >= 64 samples each: an 8-GPU share of C5) lasts as long as its heaviest pixel while
-                // most of its waves are done far earlier, and a wave's iteration takes the same time at 1 to 4 waves per SIMD:
-                // eight frames at a time on an eighth of the waves each (C5's 1/8 share, one mrt_redraw per frame: 885
-                // Msamples/s at 0.41 lane utilisation with 2 frames in flight on all waves -> 2,490 at 0.88).  Large scenes:
-                // a half (their pixels' chains differ 10 x; every large scene measured gains or stays within 1 %).
-                const bool starved = !counter && c->locals.samples_per_frame >= 64u && (uint64_t)c->n_tiles < 2ull * c->n_waves &&
-                                     c->n_tiles > c->n_waves / mrt_ctx::kMaxFrameSlots;
-                // Chains of a few bounces (the reference's default: ONE sample per frame): a frame is bound by its longest
-                // path -- up to ray_depth wave-iterations in sequence -- not by throughput, and every iteration is shorter
-                // with fewer resident waves (round 3: 20 / 8 waves per CU 0.74 / 0.42 ms per 1080p frame): a quarter of
-                // the waves, four frames side by side (round 4: 8 frames on 4 waves per CU each 9,030 Msamples/s against
-                // 4,990 for 2 on 8; the controller goes on from here).
-                const bool short_chains = c->locals.samples_per_frame < 4u && (uint64_t)c->n_tiles * 4u >= 2ull * c->n_waves;
-                c->width_div = starved ? mrt_ctx::kMaxFrameSlots : short_chains ? 4u :
-                               (!counter && c->n_members > 1024u && c->n_tiles >= 4u * c->n_waves) ? 2u : 1u;
-                c->width_valid_from = c->frame_seq + std::max(2u, c->width_div);
-                c->stat_base.valid = c->stat_last.valid = false;
-                c->width_prev = 0; c->width_settled = false; c->width_timing = false;
-                c->width_low_windows = 0;
-                c->slot_mult = 1; c->mult_prev = 1;
-            }
-            // The host may not run further ahead than the frames in flight: before a slot is used again, its previous frame's
-            // render kernel has completed (a swap-chain's back-pressure; the GPU still holds a full set of frames, queued or
-            // running).  It bounds the queued work and is what lets the samples below arrive while they can still matter -- a
-            // caller that issues its redraws in one burst would otherwise see none of them before its last call.
-            {
-                mrt_ctx::FrameSlot& Own = c->slot[c->frame_seq % c->frame_slots];
-                if (Own.stats_pending) HIP_TRY(c, hipEventSynchronize(Own.stats_ready));
-            }
-            // lane-utilisation samples that have landed (an event that is not ready yet is looked at next time)
-            for (uint32_t i = 0; i < c->frame_slots; i++) {
-                mrt_ctx::FrameSlot& T = c->slot[i];
-                if (!T.stats_pending || hipEventQuery(T.stats_ready) != hipSuccess) continue;
-                T.stats_pending = false;
-                if (T.stats_seq < c->width_valid_from) continue;
-                mrt_ctx::LaneStat st{T.stats_seq, c->h_stats[3 * i], c->h_stats[3 * i + 2], true};
-                if (!c->stat_base.valid || st.seq < c->stat_base.seq) c->stat_base = st;
-                if (!c->stat_last.valid || st.seq > c->stat_last.seq) c->stat_last = st;
-            }
-            (void)hipGetLastError();        // (hipEventQuery's hipErrorNotReady is not an error)
-            // A measurement window: from the first frame launched at the current width with the pipeline full, over
-            // 2 x (frames in flight) + 2 frames -- their lane utilisation (the samples above) and, the calls being paced by
-            // the completions (the back-pressure above), their rate on the host's clock.
-            const uint32_t in_flight = std::max(2u, c->width_div) * c->slot_mult;
-            const auto now = std::chrono::steady_clock::now();
-            if (!c->width_settled && !c->width_timing && c->frame_seq >= c->width_valid_from) {
-                c->width_timing = true;
-                c->width_t0_seq = c->frame_seq;
-                c->width_t0 = now;
-            }
-            // (... and over at least 20 ms: frames of a fifth of a millisecond -- C1, 1 spp -- filled a window in 2-3 ms of host time,
-            // whose jitter decided 1 trial in 9 the wrong way)
-            if (c->width_timing && c->frame_seq >= c->width_t0_seq + 2u * in_flight + 2u &&
-                std::chrono::duration<double>(now - c->width_t0).count() >= 0.020 && c->stat_base.valid && c->stat_last.valid &&
-                c->stat_last.seq > c->stat_base.seq && c->stat_last.slots > c->stat_base.slots && c->stat_last.hits >= c->stat_base.hits) {
-                const double util = (double)(c->stat_last.hits - c->stat_base.hits) / (double)(c->stat_last.slots - c->stat_base.slots);
-                const double rate = (double)(c->frame_seq - c->width_t0_seq) / std::max(1e-9, std::chrono::duration<double>(now - c->width_t0).count());
-                uint32_t next_div = c->width_div, next_mult = c->slot_mult;
-                static const bool trace = std::getenv("MRT_TRACE_WIDTH") != nullptr;      // diagnostics: every decision, on stderr
-                if (trace) std::fprintf(stderr, "mrt width: frame %u: div %u x %u, window %u frames, utilisation %.4f, %.2f frames/s%s\n",
-                                        c->frame_seq, c->width_div, c->slot_mult, c->frame_seq - c->width_t0_seq, util, rate,
-                                        c->width_prev != 0 ? " (trial)" : "");
-                if (c->width_prev != 0) {                    // a trial ends: keep the new setting only if it pays
-                    if (rate < 1.03 * c->width_prev_rate) { next_div = c->width_prev; next_mult = c->mult_prev; c->width_settled = true; }
-                    c->width_prev = 0;
-                }
-                if (!c->width_settled) {
-                    // narrower only while a launch's waves still get at least two tiles each; else more frames side by side
-                    const uint32_t cand = c->width_div == 1u ? 4u : c->width_div * 2u;
-                    const bool can_narrow = cand <= mrt_ctx::kMaxFrameSlots && (uint64_t)c->n_tiles * cand >= 2ull * c->n_waves && c->n_waves >= cand;
-                    const bool can_add = in_flight * 2u <= mrt_ctx::kMaxFrameSlots;
-                    // (a window's utilisation scatters by a few per cent around the workload's own -- C3: 0.93 to 0.99 around 0.970,
-                    // depending on how the frames in flight happened to share the chip -- so one low window only asks for a second)
-                    // (below 0.90 one window is evidence enough: a pixel-starved share reads 0.4 to 0.8)
-                    if (util >= 0.90 && util < 0.95 && (can_narrow || can_add) && ++c->width_low_windows < 2u) {
-                        // measure again at the same setting
-                    } else if (util < 0.95 && (can_narrow || can_add)) {
-                        c->width_low_windows = 0;
-                        c->width_prev = c->width_div;
-                        c->mult_prev = c->slot_mult;
-                        c->width_prev_rate = rate;
-                        if (can_narrow) next_div = cand; else next_mult = c->slot_mult * 2u;
-                    } else {
-                        c->width_settled = true;
-                    }
-                }
-                c->width_div = next_div;
-                c->slot_mult = next_mult;
-                c->width_timing = false;
-                c->width_valid_from = c->frame_seq + std::max(2u, next_div) * next_mult;       // (the frames of the old setting drain first)
-                c->stat_base.valid = c->stat_last.valid = false;
-            }
-            want = std::min(std::max(2u, c->width_div) * c->slot_mult, mrt_ctx::kMaxFrameSlots);
-        }
-        if (want != c->frame_slots) {
-            HIP_TRY(c, sync_all(c));
-            c->frame_slots = want;
-            // the further slots' streams and colour sums now, in one go: allocated on first use each would wait for the frames in flight
-            for (uint32_t i = 0; i < want; i++) {
-                mrt_ctx::FrameSlot& T = c->slot[i];
-                HIP_TRY(c, create_slot_streams(T));
-                T.stats_pending = false;
-                if (T.pix_acc_layers != 0) continue;
-                const size_t nt = local_texels(c) ? local_texels(c) : 1;
-                HIP_TRY(c, hipMalloc(&T.d_pix_acc, nt * 16));
-                HIP_TRY(c, hipMemsetAsync(T.d_pix_acc, 0, nt * 16, c->stream));
-                T.pix_acc_layers = 1;
-            }
-        }
+        if (adaptive) MRT_TRY(schedule_frame(c, counter, &want, &frames_running));
+        MRT_TRY(set_frame_slots(c, want));
     }
     c->last_slot = (uint32_t)(c->frame_seq % c->frame_slots);
     mrt_ctx::FrameSlot& S = c->slot[c->last_slot];
@@ -1302,8 +1421,8 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
         if ((uint64_t)layers * n >= (1ull << 32) || (uint64_t)layers * c->n_tiles >= (1ull << 26))
             return fail(c, MRT_ERR_INVALID_ARG, "mrt_redraw: %u layers of colour sums over %zu pixels exceed the tile queue's range", layers, n);
         if (S.pix_acc_layers < layers) {
-            HIP_TRY(c, hipStreamSynchronize(S.stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            MRT_TRY(mrt::wait_stream(c, S.stream, "mrt_redraw: regrowing a slot's colour sums (its side stream)"));
+            MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
             if (S.d_pix_acc) (void)hipFree(S.d_pix_acc);
             S.d_pix_acc = nullptr; S.pix_acc_layers = 0;
             HIP_TRY(c, hipMalloc(&S.d_pix_acc, (size_t)layers * n * 16));
@@ -1350,8 +1469,12 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
         // (above: launch width) -- a share of the waves the chip HOLDS for this scene's kernel: a large scene's 16 per CU, not
         // the 20 of n_waves.  Shares of n_waves had made the frames in flight ask for a quarter more waves than fit: the 1/8
         // share of C5 ran at 0.82 lane utilisation instead of 0.92, C5 itself 4 % slower
+        // ... and never a smaller share than the frames that really share the chip leave (width_policy.h, width_launch_div): a
+        // caller that waits for every frame gets all of it
         const uint32_t whole = std::min(c->n_waves, mrt::render_resident_waves(p));
-        launch_waves = std::max(whole / std::max(c->width_div, 1u), 1u);
+        c->last_launch_div = mrt::width_launch_div(c->width.div, frames_running);
+        c->last_frames_running = frames_running;
+        launch_waves = std::max(whole / c->last_launch_div, 1u);
     }
     if (c->lpt_enabled && c->n_tiles > launch_waves && chain_spp >= 4u) {
         if (!S.cost_valid && c->locals.samples_per_frame >= 8u * c->pilot_spp) {
@@ -1366,12 +1489,18 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
         }
     }
     const uint32_t ev = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
+    if (c->d_wave_log) {            // diagnostic (mrt_debug_wave_log): the frame's own part of the ring, cleared (a narrow launch leaves most of it unwritten)
+        p.wave_log = c->d_wave_log + (size_t)(c->frame_seq % mrt_ctx::kWaveLogFrames) * c->wave_log_waves * 4;
+        HIP_TRY(c, hipMemsetAsync(p.wave_log, 0, c->wave_log_waves * 4 * sizeof(unsigned long long), S.stream));
+    }
     S.queue_dirty = true;                        // until this frame's last finalize pass has been queued
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], S.stream));
     int e = mrt::launch_render(p, false, launch_waves, S.stream, &c->last_launch[0]);
     if (e) return fail(c, MRT_ERR_HIP, "render launch failed: %s", hipGetErrorString((hipError_t)e));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], S.stream));
     HIP_TRY(c, hipEventRecord(S.render_done, S.stream));
+    S.render_pending = true;
+    S.render_seq = c->frame_seq;
     if (adaptive) {         // the launch-width controller's sample: cumulative world_hit calls and lane slots after this kernel
         // (counters 1 .. 3 in ONE copy: world_hit calls and lane slots of the same instant)
         HIP_TRY(c, hipMemcpyAsync(c->h_stats + 3 * c->last_slot, c->d_counters + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream));
@@ -1458,14 +1587,14 @@ int mrt_debug_read_pixel_costs(mrt_ctx* c, uint32_t* out, size_t cap) {
     const size_t n = local_texels(c);
     if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_read_pixel_costs: need %zu", n);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     const mrt_ctx::FrameSlot& S = c->slot[c->last_slot];
     std::vector<uint32_t> tmp(n * 4), layer(n * 4);
     HIP_TRY(c, hipMemcpyAsync(tmp.data(), (const char*)S.d_pix_acc + (size_t)S.cost_first_layer * n * 16, n * 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
     for (uint32_t b = 1; b < S.cost_layers; b++) {       // counter mode: a pixel's cost is the sum over its blocks
         HIP_TRY(c, hipMemcpyAsync(layer.data(), (const char*)S.d_pix_acc + (size_t)(S.cost_first_layer + b) * n * 16, n * 16, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
         for (size_t i = 0; i < n; i++) tmp[4 * i + 3] += layer[4 * i + 3];
     }
     for (size_t i = 0; i < n; i++) out[i] = tmp[4 * i + 3];
@@ -1567,7 +1696,7 @@ int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_ou
     for (size_t i = 0; i < 6 * n; i++)
         if (!(std::fabs(rays[i]) <= 2.0e7f)) return fail(c, MRT_ERR_INVALID_ARG, "mrt_debug_world_hit: ray %zu is not finite or beyond 2e7", i / 6);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     // rays become the texels of an 8-pixel-wide virtual image (one 8x8 tile per 64 rays), padded with copies of ray 0
     const size_t n_pad = (n + 63) / 64 * 64;
     const size_t words = need_words ? need_words : 1;
@@ -1596,7 +1725,9 @@ int mrt_debug_world_hit(mrt_ctx* c, const float* rays, size_t n, int32_t* hit_ou
     p.n_blocks = 1; p.pix_stride = 0; p.queue_layers = 1; p.lane_frames = 1;
     p.dbg_rays = d_rays; p.dbg_hit = d_hit; p.dbg_cand = d_cand; p.dbg_words = (uint32_t)words;
     int le = mrt::launch_debug_world_hit(p, c->n_waves, c->stream);
-    if (le == 0) e = hipStreamSynchronize(c->stream);
+    int ws = MRT_OK;
+    if (le == 0) ws = mrt::wait_stream(c, c->stream, "mrt_debug_world_hit");
+    if (ws != MRT_OK) { cleanup(); return ws; }
     if (le != 0 || e != hipSuccess) { cleanup(); return fail(c, MRT_ERR_HIP, "mrt_debug_world_hit: launch failed: %s", hipGetErrorString(le ? (hipError_t)le : e)); }
     std::vector<int32_t> hits(n_pad * 2);
     e = hipMemcpy(hits.data(), d_hit, hits.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -1658,7 +1789,7 @@ int mrt_debug_set_tile_sort(mrt_ctx* c, int enabled) {
 int mrt_debug_set_schedule(mrt_ctx* c, uint32_t pilot_spp, int waves_per_cu) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     c->pilot_spp = pilot_spp ? pilot_spp : 1;
     c->waves_per_cu_override = waves_per_cu;
     const uint32_t frames = c->frames_done;
@@ -1680,6 +1811,57 @@ int mrt_debug_lds_layout(uint32_t n_members, uint32_t n_nodes, uint32_t levels, 
     return MRT_OK;
 }
 
+int mrt_set_wait_timeout(mrt_ctx* c, double seconds) {
+    if (!c || !(seconds >= 0.0) || !std::isfinite(seconds)) return MRT_ERR_INVALID_ARG;
+    c->wait_timeout_s = seconds;
+    return MRT_OK;
+}
+
+int mrt_get_schedule(mrt_ctx* c, uint32_t out[6]) {
+    if (!c || !out) return MRT_ERR_INVALID_ARG;
+    out[0] = c->width.div; out[1] = c->width.mult; out[2] = c->width.settled;
+    out[3] = c->width.div ? mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots) : c->frame_slots;
+    out[4] = c->last_launch_div;
+    out[5] = c->slots_probed ? c->max_slots : 0u;        // 0 = not measured yet (no setting has asked for more than two frames)
+    return MRT_OK;
+}
+
+int mrt_set_schedule_hint(mrt_ctx* c, uint32_t div, uint32_t mult) {
+    if (!c) return MRT_ERR_INVALID_ARG;
+    if (div == 0 && mult == 0) {
+        c->hint_div = c->hint_mult = 0;
+    } else {
+        if (div < 1 || div > mrt_ctx::kMaxFrameSlots || mult < 1 || mult > 4 || std::max(2u, div) * mult > mrt_ctx::kMaxFrameSlots)
+            return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_schedule_hint: div %u x mult %u (div 1..8, mult 1..4, max(2, div) x mult <= 8)", div, mult);
+        c->hint_div = div; c->hint_mult = mult;
+    }
+    c->width.div = 0;                   // the next redraw takes the hint (or starts measuring again)
+    return MRT_OK;
+}
+
+int mrt_debug_width_policy(int op, const uint32_t workload[6], uint32_t state[7], double util, double rate) {
+    if (!workload || !state || op < 0 || op > 2) return MRT_ERR_INVALID_ARG;
+    mrt::WidthWorkload w;
+    w.n_tiles = workload[0]; w.n_waves = workload[1]; w.max_slots = workload[2]; w.spp = workload[3]; w.n_members = workload[4]; w.counter = workload[5];
+    mrt::WidthState s;
+    float pr;
+    std::memcpy(&pr, &state[6], 4);
+    s.div = state[0]; s.mult = state[1]; s.prev_div = state[2]; s.prev_mult = state[3]; s.low_windows = state[4]; s.settled = state[5]; s.prev_rate = pr;
+    if (op == 0) mrt::width_policy_start(s, w);
+    else if (op == 1) { mrt::WidthWindow m; m.util = util; m.rate = rate; mrt::width_policy_step(s, w, m); }
+    else { state[0] = mrt::width_launch_div(s.div, (uint32_t)util); return MRT_OK; }
+    pr = (float)s.prev_rate;
+    state[0] = s.div; state[1] = s.mult; state[2] = s.prev_div; state[3] = s.prev_mult; state[4] = s.low_windows; state[5] = s.settled;
+    std::memcpy(&state[6], &pr, 4);
+    return MRT_OK;
+}
+
+int mrt_debug_stream_concurrency(mrt_ctx* c, uint32_t streams, float* out) {
+    if (!c || !out || streams < 2 || streams > mrt_ctx::kMaxFrameSlots) return MRT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return probe_stream_concurrency(c, streams, out);
+}
+
 int mrt_debug_set_frames_in_flight(mrt_ctx* c, int slots) {
     if (!c || slots < 0 || slots > (int)mrt_ctx::kMaxFrameSlots) return MRT_ERR_INVALID_ARG;
     c->frame_slots_override = slots;
@@ -1699,7 +1881,9 @@ int mrt_debug_arith(mrt_ctx* c, int mode, const uint32_t bits_range[4], uint64_t
     if (e == hipSuccess) e = (hipError_t)mrt::launch_arith_check(mode, bits_range, count, seed, d_out, c->stream);
     unsigned long long host[3] = {0, 0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(host, d_out, sizeof host, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    int ws = MRT_OK;
+    if (e == hipSuccess) ws = mrt::wait_stream(c, c->stream, "mrt_debug_arith");
+    if (ws != MRT_OK) return ws;            // (stalled: d_out is left to the process)
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(c, MRT_ERR_HIP, "mrt_debug_arith failed: %s", hipGetErrorString(e));
     for (int k = 0; k < 3; k++) out[k] = host[k];
@@ -1718,7 +1902,9 @@ int mrt_debug_arith_pairs(mrt_ctx* c, const float* x, const float* y, size_t n, 
     if (e == hipSuccess) e = hipMemcpyAsync(d_xy + n, y, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = (hipError_t)mrt::launch_arith_pairs(d_xy, d_xy + n, (uint32_t)n, d_o, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, 6 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    int ws = MRT_OK;
+    if (e == hipSuccess) ws = mrt::wait_stream(c, c->stream, "mrt_debug_arith_pairs");
+    if (ws != MRT_OK) return ws;
     (void)hipFree(d_xy);
     if (d_o) (void)hipFree(d_o);
     if (e != hipSuccess) return fail(c, MRT_ERR_HIP, "mrt_debug_arith_pairs failed: %s", hipGetErrorString(e));
@@ -1728,14 +1914,14 @@ int mrt_debug_arith_pairs(mrt_ctx* c, const float* x, const float* y, size_t n, 
 int mrt_sync(mrt_ctx* c) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     return MRT_OK;
 }
 
 int mrt_reset(mrt_ctx* c) {
     if (!c) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
+    MRT_TRY(mrt::wait_all(c, __func__));
     const size_t bytes = local_texels(c) * 4 * sizeof(float);
     HIP_TRY(c, hipMemsetAsync(c->d_fb[0], 0, bytes, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_fb[1], 0, bytes, c->stream));
@@ -1767,7 +1953,7 @@ int mrt_set_rng_shuffle(mrt_ctx* c, const uint32_t s[4]) {
 int mrt_set_rng_mode(mrt_ctx* c, uint32_t mode) {
     if (!c || mode > MRT_RNG_COUNTER) return MRT_ERR_INVALID_ARG;
     c->locals.rng_mode = mode;
-    c->width_div = 0;
+    c->width.div = 0;
     return MRT_OK;
 }
 
@@ -1780,7 +1966,7 @@ int mrt_set_draw_counting(mrt_ctx* c, int enabled) {
 int mrt_set_samples_per_frame(mrt_ctx* c, uint32_t spp) {
     if (!c) return MRT_ERR_INVALID_ARG;
     c->locals.samples_per_frame = spp;
-    c->width_div = 0;
+    c->width.div = 0;
     return MRT_OK;
 }
 
@@ -1803,7 +1989,7 @@ int mrt_read_framebuffer(mrt_ctx* c, float* out, size_t cap) {
     const size_t n = local_texels(c) * 4;
     if (cap < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_read_framebuffer: need %zu floats", n);
     HIP_TRY(c, hipMemcpyAsync(out, src, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
     return MRT_OK;
 }
 
@@ -1812,7 +1998,7 @@ int mrt_read_counters(mrt_ctx* c, mrt_counters* out) {
     HIP_TRY(c, hipSetDevice(c->device));
     unsigned long long h[5];
     HIP_TRY(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
     out->samples = h[0]; out->world_hit_calls = h[1]; out->rng_draws = h[2]; out->lane_slots = h[3];
     out->member_tests = h[4];
     out->sweep_records = c->n_padded;
@@ -1824,31 +2010,38 @@ int mrt_debug_read_counters(mrt_ctx* c, uint64_t out[16]) {
     if (!c || !out) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpyAsync(out, c->d_counters, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
     return MRT_OK;
 }
 
 // diagnostic: enable / read the per-wave log {t_start, t_end (100 MHz ticks), trips, bounces}
-// that -DMRT_STAMPS builds write; out == NULL just (re)allocates it for the current shard.
-int mrt_debug_wave_log(mrt_ctx* c, uint64_t* out, size_t cap_waves, size_t* n_waves) {
-    if (!c) return MRT_ERR_INVALID_ARG;
+// that -DMRT_STAMPS builds write; out == NULL just (re)allocates it for the current shard.  The log is a ring over the last
+// kWaveLogFrames frames (frames in flight overlap): `back` = 0 reads the most recent frame's, 1 the one before, ...
+int mrt_debug_wave_log_frame(mrt_ctx* c, uint32_t back, uint64_t* out, size_t cap_waves, size_t* n_waves) {
+    if (!c || back >= mrt_ctx::kWaveLogFrames) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = c->n_waves;
     if (n_waves) *n_waves = n;
     if (!c->d_wave_log || c->wave_log_waves != n) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        MRT_TRY(mrt::wait_all(c, __func__));
         if (c->d_wave_log) (void)hipFree(c->d_wave_log);
         c->d_wave_log = nullptr;
-        HIP_TRY(c, hipMalloc(&c->d_wave_log, n * 4 * sizeof(uint64_t)));
-        HIP_TRY(c, hipMemset(c->d_wave_log, 0, n * 4 * sizeof(uint64_t)));
+        HIP_TRY(c, hipMalloc(&c->d_wave_log, mrt_ctx::kWaveLogFrames * n * 4 * sizeof(uint64_t)));
+        HIP_TRY(c, hipMemset(c->d_wave_log, 0, mrt_ctx::kWaveLogFrames * n * 4 * sizeof(uint64_t)));
         c->wave_log_waves = n;
     }
     if (out) {
         if (cap_waves < n) return fail(c, MRT_ERR_TOO_SMALL, "mrt_debug_wave_log: need %zu waves", n);
-        HIP_TRY(c, hipMemcpyAsync(out, c->d_wave_log, n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->frame_seq <= back) return fail(c, MRT_ERR_STATE, "mrt_debug_wave_log: frame %u back has not been rendered", back);
+        MRT_TRY(mrt::wait_all(c, __func__));
+        const unsigned long long* src = c->d_wave_log + (size_t)((c->frame_seq - 1 - back) % mrt_ctx::kWaveLogFrames) * n * 4;
+        HIP_TRY(c, hipMemcpyAsync(out, src, n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        MRT_TRY(mrt::wait_stream(c, c->stream, __func__));
     }
     return MRT_OK;
+}
+int mrt_debug_wave_log(mrt_ctx* c, uint64_t* out, size_t cap_waves, size_t* n_waves) {
+    return mrt_debug_wave_log_frame(c, 0, out, cap_waves, n_waves);
 }
 
 int mrt_kernel_ms_history(mrt_ctx* c, float* ms, size_t cap, size_t* n_out) {
@@ -1858,7 +2051,7 @@ int mrt_kernel_ms_history(mrt_ctx* c, float* ms, size_t cap, size_t* n_out) {
     if (n > cap) n = cap;
     for (size_t i = 0; i < n; i++) {          // ms[0] = oldest of the n most recent redraws
         const uint32_t slot = (uint32_t)((c->timed_frames - n + i) % mrt_ctx::kEventRing);
-        HIP_TRY(c, hipEventSynchronize(c->ev_stop[slot]));
+        MRT_TRY(mrt::wait_event(c, c->ev_stop[slot], "mrt_kernel_ms_history: the render kernel's stop event"));
         HIP_TRY(c, hipEventElapsedTime(&ms[i], c->ev_start[slot], c->ev_stop[slot]));
     }
     *n_out = n;

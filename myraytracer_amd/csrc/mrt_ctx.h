@@ -5,8 +5,10 @@
 
 #include <chrono>
 #include <string>
+#include <vector>
 
 #include "mrt_internal.h"
+#include "width_policy.h"
 
 struct mrt_ctx {
     int device = 0;
@@ -91,25 +93,26 @@ struct mrt_ctx {
         hipEvent_t stats_ready = nullptr;
         uint64_t stats_seq = 0;
         bool stats_pending = false;
+        bool render_pending = false;           // a render kernel of this slot has been launched and not yet been seen complete
+        uint64_t render_seq = 0;               // its frame (diagnostics of a stalled wait)
     } slot[kMaxFrameSlots];
-    // Launch width (redraw_frames): a frame is launched on n_waves / width_div persistent waves and max(2, width_div) frames are
-    // in flight, so that the chip stays full.  Narrow launches pack the lanes better (more pixels per lane in sequence: the
-    // launch's tail, in which lanes idle until their wave's longest pixel ends, is the same length but a smaller share) at the
-    // price of a longer frame latency -- and they do not always pay (C3 / C4, 0.98 / 0.99 lane utilisation at full width, lose
-    // 1-4 % at a half; C2 loses 4 % at a half and gains 18 % at a quarter).  So: width_div starts from what is known up front
-    // (8 for a pixel-starved shard of long chains, 4 for chains of a few bounces, 2 for large scenes, else 1); while the measured lane utilisation at the
-    // current width is below 0.95 a narrower width is TRIED (x 4 from full width, then x 2) -- or, where the frame has too few
-    // tiles to be launched any narrower, twice the frames in flight -- and kept only if the measured frame rate rises by 3 %,
-    // else the previous setting returns and stays.  Scheduling only: the images do not change.
-    uint32_t width_div = 0;                         // 0 = not chosen yet for the current workload
-    uint32_t slot_mult = 1;                         // frames in flight = max(2, width_div) x slot_mult (<= kMaxFrameSlots): frames too
-                                                    // small or too short to fill the chip gain from more of them side by side
-                                                    // (C1: 1,450 tiles for 5,120 waves: 2 / 4 / 8 in flight 2,470 / 4,040 / 6,960 Msamples/s)
-    uint32_t width_prev = 0, mult_prev = 1;         // what a running trial would return to (width_prev 0 = no trial)
-    bool width_settled = false;                     // no further trials for this workload
-    uint32_t width_low_windows = 0;                 // consecutive windows below the utilisation threshold (a trial takes two)
-    double width_prev_rate = 0.0;                   // frames / s measured at width_prev
-    uint64_t width_valid_from = 0;                  // frame_seq from which samples and timings belong to the current width
+    // Launch width (redraw_frames; the policy itself: width_policy.h): a frame is launched on 1 / width.div of the persistent
+    // waves the chip holds and max(2, width.div) x width.mult frames are in flight, so that the chip stays full.  Narrow launches
+    // pack the lanes better (more pixels per lane in sequence: the launch's tail, in which lanes idle until their wave's longest
+    // pixel ends, is the same length but a smaller share) at the price of a longer frame latency -- and they do not always pay
+    // (C3 / C4, 0.98 / 0.99 lane utilisation at full width, lose 1-4 % at a half; C2 loses 4 % at a half and gains 18 % at a
+    // quarter).  So the setting is MEASURED: trials while the utilisation is low, kept only if the frame rate rises by 3 %.
+    // Scheduling only: the images do not change.
+    mrt::WidthState width;                          // div 0 = not chosen yet for the current workload
+    uint32_t hint_div = 0, hint_mult = 0;           // mrt_set_schedule_hint: the caller's setting (0 = the controller decides)
+    uint32_t max_slots = kMaxFrameSlots;            // frames that can really run side by side (probe_stream_concurrency)
+    bool slots_probed = false;
+    uint32_t last_launch_div = 1, last_frames_running = 0;   // mrt_get_schedule: what the most recent launch was issued with
+    // settled settings by workload, so that a change of camera / samples per frame / scene and back does not start the trials
+    // over (and a viewer that moves its camera every frame still reaches one)
+    struct WidthMemo { uint32_t n_tiles, spp, large, counter, n_spheres, div, mult; };
+    std::vector<WidthMemo> width_memo;
+    uint64_t width_valid_from = 0;                  // frame_seq from which samples and timings belong to the current setting
     bool width_timing = false;                      // a measurement window is open: since frame width_t0_seq, at width_t0
     uint64_t width_t0_seq = 0;
     std::chrono::steady_clock::time_point width_t0;
@@ -122,7 +125,8 @@ struct mrt_ctx {
     uint32_t pilot_spp = 2;
     int waves_per_cu_override = 0;
     bool lpt_enabled = true;
-    unsigned long long* d_wave_log = nullptr;   // diagnostic, see mrt_debug_wave_log
+    static constexpr uint32_t kWaveLogFrames = 32;
+    unsigned long long* d_wave_log = nullptr;   // diagnostic, see mrt_debug_wave_log: a ring of kWaveLogFrames frames' logs
     size_t wave_log_waves = 0;
 
     // multi-GPU gather (multi_gpu.cpp): on the root, the full frame assembled from every shard's bands
@@ -149,6 +153,12 @@ struct mrt_ctx {
     int batch_form = 0;                    // 0 automatic, 1 always "a lane keeps its pixel for the batch's frames", 2 always queue layers
     float set_world_ms = 0.0f;             // host time of the last scene upload (hierarchy build + copies)
 
+    // Every blocking host wait of the library polls with this deadline (seconds; 0 = no deadline) and fails with
+    // MRT_ERR_STALLED, naming the wait, instead of hanging (mrt_set_wait_timeout).  A context that has stalled once stays
+    // failed: its queued work may never finish, so mrt_destroy then releases what it can without waiting.
+    double wait_timeout_s = 120.0;
+    bool stalled = false;
+
     std::string err;
 };
 
@@ -160,7 +170,20 @@ int fail(mrt_ctx* ctx, int status, const char* fmt, ...) __attribute__((format(p
 inline uint32_t total_bands(uint32_t height) { return (height + kBandRows - 1) / kBandRows; }
 inline size_t local_texels(const mrt_ctx* c) { return (size_t)c->local_bands * kBandRows * c->args.width; }
 
+// Bounded host waits (api.cpp): poll the event / stream until it is complete or the context's deadline has passed; `what`
+// names the wait in the error message.  Return an mrt_status.
+int wait_event(mrt_ctx* c, hipEvent_t ev, const char* what);
+int wait_stream(mrt_ctx* c, hipStream_t s, const char* what);
+// everything this context has in flight: the side streams, then the caller's stream
+int wait_all(mrt_ctx* c, const char* what);
+
 }  // namespace mrt
+
+#define MRT_TRY(expr)                      \
+    do {                                   \
+        const int st_ = (expr);            \
+        if (st_ != MRT_OK) return st_;     \
+    } while (0)
 
 #define HIP_TRY(ctx, expr)                                                                     \
     do {                                                                                       \

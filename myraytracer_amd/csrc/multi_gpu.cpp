@@ -32,7 +32,7 @@ int ensure_gather_buffer(mrt_ctx* R) {
     const size_t need = band_bytes(R) * R->local_bands * R->shard_world;
     if (R->d_gather && R->gather_bytes == need) return MRT_OK;
     HIP_TRY(R, hipSetDevice(R->device));
-    if (R->d_gather) { HIP_TRY(R, hipStreamSynchronize(R->stream)); (void)hipFree(R->d_gather); R->d_gather = nullptr; }
+    if (R->d_gather) { MRT_TRY(mrt::wait_stream(R, R->stream, __func__)); (void)hipFree(R->d_gather); R->d_gather = nullptr; }
     HIP_TRY(R, hipMalloc((void**)&R->d_gather, need ? need : 16));
     R->gather_bytes = need;
     return MRT_OK;
@@ -198,7 +198,7 @@ int mrt_gather_rccl(mrt_ctx* c, void* nccl_comm, uint32_t root) {
     if ((st = ensure_gather_buffer(c)) != MRT_OK) return st;
     const size_t stage_need = local_floats * sizeof(float) * world;
     if (!c->d_gather_stage || c->gather_stage_bytes != stage_need) {
-        if (c->d_gather_stage) { HIP_TRY(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_gather_stage); c->d_gather_stage = nullptr; }
+        if (c->d_gather_stage) { MRT_TRY(mrt::wait_stream(c, c->stream, __func__)); (void)hipFree(c->d_gather_stage); c->d_gather_stage = nullptr; }
         HIP_TRY(c, hipMalloc((void**)&c->d_gather_stage, stage_need ? stage_need : 16));
         c->gather_stage_bytes = stage_need;
     }
@@ -234,7 +234,7 @@ int mrt_read_gathered(mrt_ctx* R, float* out, size_t cap) {
     if (cap < n) return fail(R, MRT_ERR_TOO_SMALL, "mrt_read_gathered: need %zu floats", n);
     HIP_TRY(R, hipSetDevice(R->device));
     HIP_TRY(R, hipMemcpyAsync(out, R->d_gather, n * sizeof(float), hipMemcpyDeviceToHost, R->stream));
-    HIP_TRY(R, hipStreamSynchronize(R->stream));
+    MRT_TRY(mrt::wait_stream(R, R->stream, __func__));
     return MRT_OK;
 }
 

@@ -89,7 +89,24 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(const uint32_t* __res
     if (ok) order[pos] = i;
 }
 
+// probe_stream_concurrency (api.cpp): one wave that stays resident for `ticks` of the 100 MHz wall clock and then ends -- or
+// after `max_polls` polls, whichever comes first: the exit never depends on the clock alone.  Writes the ticks it saw.
+__global__ void __launch_bounds__(64) hold_kernel(unsigned long long ticks, uint32_t max_polls, unsigned long long* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long now = t0;
+    for (uint32_t i = 0; i < max_polls && now - t0 < ticks; i++) {
+        __builtin_amdgcn_s_sleep(32);
+        now = __builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 0 && out) *out = now - t0;
+}
+
 }  // namespace
+
+int launch_hold(unsigned long long ticks, uint32_t max_polls, unsigned long long* out, void* stream) {
+    hipLaunchKernelGGL(hold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks, max_polls, out);
+    return (int)hipGetLastError();
+}
 
 int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, uint32_t n_tiles, void* stream) {
     if (n_tiles == 0) return 0;

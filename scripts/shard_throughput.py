@@ -20,6 +20,8 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 
         assert _lib.load().mrt_debug_set_schedule(st._ctx, 1, int(os.environ["MRT_WAVES_PER_CU"])) == 0
     if os.environ.get("MRT_SLOTS"):          # frames in flight
         assert _lib.load().mrt_debug_set_frames_in_flight(st._ctx, int(os.environ["MRT_SLOTS"])) == 0
+    if os.environ.get("MRT_HINT"):           # "div,mult": pin the launch schedule
+        st.set_schedule_hint(*[int(x) for x in os.environ["MRT_HINT"].split(",")])
     if os.environ.get("MRT_NOBATCH"):     # mrt_render without sharing launches among frames
         assert _lib.load().mrt_debug_set_frame_batching(st._ctx, 0) == 0
     if os.environ.get("MRT_CLUSTER"):
@@ -32,4 +34,4 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=(rank, world) if world > 
     util = (c1["world_hit_calls"] - c0["world_hit_calls"]) / max(1, c1["lane_slots"] - c0["lane_slots"])
     print(f"{scene} {w}x{h}x{spp} shard {rank}/{world} rng_mode {mode}: {dt / K * 1e3:.1f} ms/frame, per-GPU "
           f"{w * h * spp / world * K / dt * 1e-6:.1f} Msamples/s, lane utilisation {util:.3f}, "
-          f"kernel ms {[round(x) for x in st.kernel_ms_history(K)]}", flush=True)
+          f"kernel ms {[round(x) for x in st.kernel_ms_history(K)]}, schedule {st.get_schedule()}", flush=True)

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Dev helper (GPU box): pipelined wall-clock Msamples/s of one workload under the tuning switches.
-   [MRT_HIER=levels,top] [MRT_BOXES=0|1] [MRT_RNG=1] python scripts/wall_rate.py scene w h spp steps"""
+   [MRT_HIER=levels,top] [MRT_BOXES=0|1] [MRT_RNG=1] [MRT_HINT=div,mult] [MRT_READ_EVERY=1] [MRT_SHARD=rank,world]
+   python scripts/wall_rate.py scene w h spp steps"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import myraytracer_amd as M
 a = sys.argv[1:]
 scene, w, h, spp, steps = a[0], int(a[1]), int(a[2]), int(a[3]), int(a[4])
 sp, cam = (M.scene_cover(1, scene == "cover-glass") if scene.startswith("cover") else M.scene_stress(1, 100) if scene == "stress" else M.scene_stress(1, int(scene[6:])) if scene.startswith("stress") else (M.scene_default(), None))
-with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
+shard = tuple(int(x) for x in os.environ["MRT_SHARD"].split(",")) if os.environ.get("MRT_SHARD") else None
+with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=shard) as st:
     if os.environ.get("MRT_HIER"):
         st.debug_set_hierarchy(*[int(x) for x in os.environ["MRT_HIER"].split(",")])
     if os.environ.get("MRT_BOXES"):
@@ -17,6 +19,9 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
         st.debug_set_schedule(a_[0], a_[1])
     if os.environ.get("MRT_SLOTS"):
         st.debug_set_frames_in_flight(int(os.environ["MRT_SLOTS"]))
+    if os.environ.get("MRT_HINT"):              # "div,mult": pin the launch schedule
+        st.set_schedule_hint(*[int(x) for x in os.environ["MRT_HINT"].split(",")])
+    read_every = bool(os.environ.get("MRT_READ_EVERY"))     # a viewer: the framebuffer is read back after every redraw
     st.set_world(sp)
     if cam is not None: st.set_camera(cam)
     if os.environ.get("MRT_RNG"): st.set_rng_mode(int(os.environ["MRT_RNG"]))
@@ -25,10 +30,13 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1) as st:
     st.sync()
     c0 = st.read_counters()
     t0 = time.perf_counter()
-    for _ in range(steps): st.redraw()
+    for _ in range(steps):
+        st.redraw()
+        if read_every: st.read_framebuffer()
     st.sync()
     dt = time.perf_counter() - t0
     c1 = st.read_counters()
     util = (c1["world_hit_calls"] - c0["world_hit_calls"]) / max(1, c1["lane_slots"] - c0["lane_slots"])
     print(f"{scene} {w}x{h}x{spp} HIER={os.environ.get('MRT_HIER')} BOXES={os.environ.get('MRT_BOXES')} RNG={os.environ.get('MRT_RNG')}: "
-          f"{w * h * spp * steps / dt * 1e-6:.0f} Msamples/s, {dt / steps * 1e3:.1f} ms/step, lane util {util:.3f}, top {c1['sweep_records']}", flush=True)
+          f"{w * h * spp * steps / dt * 1e-6 / (shard[1] if shard else 1):.0f} Msamples/s, {dt / steps * 1e3:.1f} ms/step, lane util {util:.3f}, top {c1['sweep_records']}, "
+          f"{'read back every frame, ' if read_every else ''}schedule {st.get_schedule()}", flush=True)

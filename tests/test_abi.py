@@ -42,9 +42,10 @@ def test_every_declared_symbol_is_exported(mrt):
 def test_abi_version_and_status_strings(mrt):
     from myraytracer_amd import _lib
     L = _lib.load()
-    assert L.mrt_abi_version() == 3
+    assert L.mrt_abi_version() == 4
     assert L.mrt_status_string(0) == b"ok"
     assert L.mrt_status_string(2) == b"no usable HIP device"
+    assert L.mrt_status_string(9) == b"a wait for the GPU passed its deadline"
     assert L.mrt_last_error(None) is not None
 
 
