@@ -127,8 +127,9 @@ int mrt_debug_set_frames_in_flight(mrt_ctx* ctx, int slots);
  * launch gets under setting state[0] when `util` (as an integer) earlier frames are still queued or running. */
 int mrt_debug_width_policy(int op, const uint32_t workload[6], uint32_t state[7], double util, double rate);
 /* Diagnostic: how many of `streams` (2..8) side streams of this context really run side by side in this process -- identical
- * short clock-bounded kernels, one per stream, timed against one alone: *out = streams x t_one / t_all (hardware queues are
- * shared round-robin: HIP's default of 4 per process gives about 4).  What caps the frames in flight (mrt_get_schedule). */
+ * short clock-bounded kernels, one per stream, each stamping its start and end on the device's clock: *out = the most of them
+ * resident at one instant (hardware queues are shared round-robin: HIP's default of 4 per process gives 4).  What caps the
+ * frames in flight (mrt_get_schedule). */
 int mrt_debug_stream_concurrency(mrt_ctx* ctx, uint32_t streams, float* out);
 /* Diagnostic: per-wave log {t_start, t_end (100 MHz ticks), loop trips, bounces}, 4 u64 per 8x8
  * persistent wave, written only by the -DMRT_STAMPS build.  out == NULL allocates the log. */

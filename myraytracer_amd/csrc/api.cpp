@@ -864,7 +864,7 @@ int mrt_create(const mrt_args* args, uint64_t seed, int device, mrt_ctx** out) {
         if (hipEventCreate(&c->ev_start[i]) != hipSuccess || hipEventCreate(&c->ev_stop[i]) != hipSuccess) { c->err = "hipEventCreate failed"; return bail(MRT_ERR_HIP); }
     if (hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess) { c->err = "counter allocation failed"; return bail(MRT_ERR_HIP); }
-    if (hipHostMalloc((void**)&c->h_stats, 3 * mrt_ctx::kMaxFrameSlots * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { c->err = "pinned allocation failed"; return bail(MRT_ERR_HIP); }
+    if (hipHostMalloc((void**)&c->h_stats, 5 * mrt_ctx::kMaxFrameSlots * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { c->err = "pinned allocation failed"; return bail(MRT_ERR_HIP); }
     int st = alloc_frame_buffers(c);
     if (st != MRT_OK) return bail(st);
     *out = c;
@@ -1197,33 +1197,34 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     p.spheres = c->d_spheres; p.clusters = c->d_clusters; p.nodes = c->d_nodes; p.top_mfma = c->d_top_mfma; p.member_index = c->d_member_index; p.vec4_data = c->d_vec4; p.shade = c->d_shade; p.f32_data = c->d_f32; p.i32_data = c->d_i32;
 }
 
-// How many of `k` side streams of this process really run at a time: one clock-bounded single-wave kernel per stream (0.4 ms
-// each; launch_hold) against one alone, on the host's clock.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware
-// queues (4 unless the host set the variable before its first HIP call) and kernels of streams that share one serialise: round 4
-// measured 8 frames in flight running 2.7 at a time on the default, all 8 on 16 queues (C5's 1/8 share 1,050 -> 2,370
-// Msamples/s).  Called once per context, with nothing in flight, when the schedule first asks for more than two frames.
+// How many of `k` side streams of this process really run at a time: one clock-bounded single-wave kernel per stream (0.5 ms
+// each; launch_hold) stamps its start and end on the device's wall clock; the answer is the largest number of them resident at
+// one instant.  HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the host set the variable
+// before its first HIP call) and kernels of streams that share one serialise: round 4 measured 8 frames in flight running 2.7
+// at a time on the default, all 8 on 16 queues (C5's 1/8 share 1,050 -> 2,370 Msamples/s).  Called once per context, with
+// nothing in flight, when the schedule first asks for more than two frames.
 static int probe_stream_concurrency(mrt_ctx* c, uint32_t k, float* out) {
     if (k < 2u) k = 2u;
     if (k > mrt_ctx::kMaxFrameSlots) k = mrt_ctx::kMaxFrameSlots;
     for (uint32_t i = 0; i < k; i++) HIP_TRY(c, create_slot_streams(c->slot[i]));
     MRT_TRY(mrt::wait_all(c, "probe_stream_concurrency"));
-    const unsigned long long ticks = 40000ull;              // 0.4 ms of the 100 MHz clock
-    auto timed = [&](uint32_t n, double* seconds) -> int {
-        // (a first launch per stream outside the clock: code object load, queue creation)
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t i = 0; i < n; i++) {
-            const int e = mrt::launch_hold(ticks, 1u << 14, nullptr, c->slot[i].stream);
+    unsigned long long* const stamps = c->h_stats + 3 * mrt_ctx::kMaxFrameSlots;      // pinned, device-visible: 2 per stream
+    uint32_t best = 0;
+    for (int pass = 0; pass < 2; pass++) {           // (the first pass also pays for the code object and the queues' creation)
+        std::memset(stamps, 0, 2 * mrt_ctx::kMaxFrameSlots * sizeof(unsigned long long));
+        for (uint32_t i = 0; i < k; i++) {
+            const int e = mrt::launch_hold(50000ull, 1u << 14, stamps + 2 * i, c->slot[i].stream);
             if (e) return fail(c, MRT_ERR_HIP, "probe_stream_concurrency: launch failed: %s", hipGetErrorString((hipError_t)e));
         }
-        for (uint32_t i = 0; i < n; i++) MRT_TRY(mrt::wait_stream(c, c->slot[i].stream, "probe_stream_concurrency"));
-        *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return MRT_OK;
-    };
-    double warm = 0.0, one = 0.0, all = 0.0;
-    MRT_TRY(timed(k, &warm));
-    MRT_TRY(timed(1, &one));
-    MRT_TRY(timed(k, &all));
-    *out = (float)((double)k * one / std::max(all, 1e-9));
+        for (uint32_t i = 0; i < k; i++) MRT_TRY(mrt::wait_stream(c, c->slot[i].stream, "probe_stream_concurrency"));
+        best = 0;
+        for (uint32_t i = 0; i < k; i++) {           // at the start of kernel i: how many are resident?
+            uint32_t n = 0;
+            for (uint32_t j = 0; j < k; j++) n += (stamps[2 * j] <= stamps[2 * i] && stamps[2 * i] < stamps[2 * j + 1]) ? 1u : 0u;
+            best = std::max(best, n);
+        }
+    }
+    *out = (float)best;
     return MRT_OK;
 }
 
@@ -1235,11 +1236,11 @@ static int probe_max_slots(mrt_ctx* c) {
     MRT_TRY(probe_stream_concurrency(c, mrt_ctx::kMaxFrameSlots, &conc));
     c->slots_probed = true;
     uint32_t cap = mrt_ctx::kMaxFrameSlots;
-    while (cap > 2u && conc < 0.8f * (float)cap) cap /= 2u;
+    while (cap > 2u && conc < (float)cap) cap /= 2u;
     c->max_slots = cap;
     if (cap < mrt_ctx::kMaxFrameSlots) {
         char buf[256];
-        std::snprintf(buf, sizeof buf, "myraytracer_amd: only %.1f of %u side streams run at a time in this process: at most %u frames in flight "
+        std::snprintf(buf, sizeof buf, "myraytracer_amd: only %.0f of %u side streams run at a time in this process: at most %u frames in flight "
                       "(set GPU_MAX_HW_QUEUES=16 before the process' first HIP call: INTEGRATION.md 2a)", conc, mrt_ctx::kMaxFrameSlots, cap);
         g_err = buf;
         static const bool trace = std::getenv("MRT_TRACE_WIDTH") != nullptr;

@@ -117,7 +117,7 @@ struct mrt_ctx {
     uint64_t width_t0_seq = 0;
     std::chrono::steady_clock::time_point width_t0;
     struct LaneStat { uint64_t seq = 0, hits = 0, slots = 0; bool valid = false; } stat_base, stat_last;
-    unsigned long long* h_stats = nullptr;          // pinned, 3 x kMaxFrameSlots
+    unsigned long long* h_stats = nullptr;          // pinned, 3 x kMaxFrameSlots (+ 2 x kMaxFrameSlots: the concurrency probe's stamps)
     hipEvent_t ev_inputs = nullptr;            // scene / seeds uploads on the caller's stream
     bool inputs_dirty = true;
     uint64_t frame_seq = 0;

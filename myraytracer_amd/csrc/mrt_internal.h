@@ -146,8 +146,8 @@ constexpr uint32_t kBoxLdsCap = 1024;    // never more boxes (32 B each) than th
 // tile_order.hip: order[] = tile ids sorted by cost[] descending (bucket sort; ties in any order).
 // scratch: 1024 u32.
 int launch_sort_tiles(const uint32_t* cost, uint32_t* order, uint32_t* scratch, uint32_t n_tiles, void* stream);
-// one single-wave kernel that stays resident for `ticks` of the 100 MHz clock (at most max_polls polls); out (optional) gets
-// the ticks it saw
+// one single-wave kernel that stays resident for `ticks` of the 100 MHz clock (at most max_polls polls); out (optional, device-
+// visible) gets its {start, end} ticks
 int launch_hold(unsigned long long ticks, uint32_t max_polls, unsigned long long* out, void* stream);
 int launch_fill_seeds(uint32_t* seeds, uint64_t seed, uint32_t width, uint32_t height,
                       uint32_t shard_rank, uint32_t shard_world, uint32_t local_bands, void* stream);

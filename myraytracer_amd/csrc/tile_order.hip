@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(const uint32_t* __res
 }
 
 // probe_stream_concurrency (api.cpp): one wave that stays resident for `ticks` of the 100 MHz wall clock and then ends -- or
-// after `max_polls` polls, whichever comes first: the exit never depends on the clock alone.  Writes the ticks it saw.
+// after `max_polls` polls, whichever comes first: the exit never depends on the clock alone.  Writes {start, end} ticks.
 __global__ void __launch_bounds__(64) hold_kernel(unsigned long long ticks, uint32_t max_polls, unsigned long long* out) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long now = t0;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(64) hold_kernel(unsigned long long ticks, uint
         __builtin_amdgcn_s_sleep(32);
         now = __builtin_amdgcn_s_memrealtime();
     }
-    if (threadIdx.x == 0 && out) *out = now - t0;
+    if (threadIdx.x == 0 && out) { out[0] = t0; out[1] = now; }
 }
 
 }  // namespace

@@ -57,7 +57,8 @@ if T1 <= T0: T0, T1 = min(f["t0"].min() for f in frames), max(f["t1"].max() for 
 def overlap(a, b): return np.clip(np.minimum(b, T1) - np.maximum(a, T0), 0, None).sum()
 running = sum(overlap(f["t0"], f["t1"]) for f in frames)
 held = sum((np.clip(np.minimum(f["ge"], T1) - np.maximum(f["gs"], T0), 0, None) * GROUP).sum() for f in frames)
-wave_slots = int(os.environ.get("MRT_WAVE_SLOTS", "0")) or max(len(f["t0"]) for f in frames) * sch["div"]
+# the wave slots the chip holds for this kernel: MRT_WAVE_SLOTS (C5's large-scene kernel: 256 CUs x 16), else the steady launches' width x div
+wave_slots = int(os.environ.get("MRT_WAVE_SLOTS", "0")) or int(np.median([len(f["t0"]) for f in frames[len(frames) // 2:]])) * sch["div"]
 cap = wave_slots * (T1 - T0)
 busy_lanes = sum(f["hits"].sum() for f in frames); lane_slots = sum(64 * f["trips"].sum() for f in frames)
 print(f"{scene} {w}x{h}x{spp} shard {rank}/{world}: schedule div {sch['div']} x {sch['mult']}, {slots_in_flight} frames in flight, "
