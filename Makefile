@@ -56,3 +56,9 @@ clean:
 stamps: $(SRCS) $(HDRS) $(OBJDIR)/build_id.cpp
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $(LIBDIR)/libmyraytracer_amd_stamps.so $(SRCS) $(OBJDIR)/build_id.cpp -ldl
+
+# experiment builds (never the product): make variant NAME=slots16 FLAGS="-DMRT_MAX_SLOTS=16" -> lib/libmyraytracer_amd_slots16.so,
+# selected at run time by MRT_LIB_OVERRIDE (bench.py refuses a headline from it)
+variant: $(SRCS) $(HDRS) $(OBJDIR)/build_id.cpp
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) $(FLAGS) -shared -o $(LIBDIR)/libmyraytracer_amd_$(NAME).so $(SRCS) $(OBJDIR)/build_id.cpp -ldl

@@ -71,7 +71,7 @@ def launch_ranks(n, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-               GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "16"))      # frames in flight of pixel-starved shards (api.cpp)
+               GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "32"))      # frames in flight of pixel-starved shards (api.cpp)
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -207,6 +207,86 @@ def abi_single_process_leg(a, n, width, height, spp, ref_rgb):
                     "frames; wall time incl. the gather, after one warm-up frame"}
 
 
+def load_schedules():
+    """profiles/schedules.json: the launch schedule (div, mult -- mrt_get_schedule) each workload settled at in a measuring run
+    on this hardware (scripts/settle_schedules.py), keyed "<config>_n<gpus>".  Pinning it (mrt_set_schedule_hint) makes two runs
+    schedule alike: the controller decides on the host's wall clock and needs tens of frames (C2: 60) to get there."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "schedules.json")))
+    except Exception:
+        return {}
+
+
+def settle(st, step, fence, all_settled, max_frames, max_seconds):
+    """Run untimed steps until the launch schedule is final for this workload (every rank's), or the cap.  Returns the steps run."""
+    n, t0 = 0, time.perf_counter()
+    while n < max_frames and time.perf_counter() - t0 < max_seconds:
+        if all_settled(st.get_schedule()["settled"]):
+            break
+        step()
+        n += 1
+    fence()
+    return n
+
+
+def other_config_rates(M, schedules, budget_s):
+    """After the headline's timed region (never inside it), N = 1: BASELINE.json's other configs and the share one GPU of an
+    8-GPU C5 run renders, each on a fresh context -- pinned schedule where profiles/schedules.json has one, else measured until
+    settled --, pipeline filled, then `steps` timed mrt_redraw calls; samples counted and asserted.  Short legs: a few steps each."""
+    legs = [   # name, scene, width, height, spp, depth, shard, warm-up frames (pinned schedule), timed steps, schedule key
+        ("c1", "default", 400, 225, 16, 8, None, 600, 3000, "c1_n1"),
+        ("c2", "cover", 1200, 675, 64, 50, None, 30, 150, "c2_n1"),
+        ("c4", "cover-glass", 3840, 2160, 1024, 50, None, 2, 3, "c4_n1"),
+        ("c5", "stress", 1920, 1080, 4096, 50, None, 5, 4, "c5_n1"),
+        # (sixteen frames in flight: the pipeline's start -- sixteen launches at once -- takes two rounds of frames to even out)
+        ("c5_share_1_of_8", "stress", 1920, 1080, 4096, 50, (0, 8), 32, 32, "c5_n8"),
+    ]
+    out, t_begin = {}, time.perf_counter()
+    for name, scene, w, h, spp, depth, shard, warm, steps, key in legs:
+        if time.perf_counter() - t_begin > budget_s:
+            out[name] = {"skipped": f"the {budget_s:.0f} s budget of the other configs was spent"}
+            continue
+        spheres, cam = (M.scene_cover(1, scene == "cover-glass") if scene.startswith("cover") else
+                        M.scene_stress(1, 100) if scene == "stress" else (M.scene_default(), None))
+        try:
+            with M.State(M.Args(w, h, spp, depth, 1.0), seed=1, shard=shard) as s2:
+                s2.set_world(spheres)
+                if cam is not None:
+                    s2.set_camera(cam)
+                s2.set_draw_counting(False)
+                pin = schedules.get(key)
+                settle_frames = 0
+                if pin:
+                    s2.set_schedule_hint(int(pin["div"]), int(pin["mult"]))
+                else:
+                    settle_frames = settle(s2, s2.redraw, s2.sync, bool, 400, 12.0)
+                for _ in range(warm if pin else 0):     # fill the pipeline
+                    s2.redraw()
+                s2.sync()
+                c0 = s2.read_counters()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    s2.redraw()
+                s2.sync()
+                dt = time.perf_counter() - t0
+                c1 = s2.read_counters()
+                sch = s2.get_schedule()
+            n_px = w * h if shard is None else sum(min(8, h - 8 * b) * w for b in range((h + 7) // 8) if b % shard[1] == shard[0])
+            assert c1["samples"] - c0["samples"] == n_px * spp * steps, (name, c1["samples"] - c0["samples"], n_px * spp * steps)
+            out[name] = {"value": n_px * spp * steps / dt * 1e-6, "unit": "Msamples/s" + (" per GPU" if shard else ""),
+                         "ms_per_step": dt / steps * 1e3, "steps": steps, "settled": [sch["div"], sch["mult"]],
+                         "schedule_final": sch["settled"], "frames_in_flight": sch["frames_in_flight"],
+                         "schedule_source": "profiles/schedules.json (pinned)" if pin else f"measured: {settle_frames} untimed frames",
+                         "lane_utilisation": (c1["world_hit_calls"] - c0["world_hit_calls"]) / max(1, c1["lane_slots"] - c0["lane_slots"]),
+                         "workload": f"{scene} {w}x{h}x{spp} depth {depth}" + (f", rank {shard[0]} of {shard[1]}'s interleaved 8-row bands" if shard else "")}
+        except Exception as e:           # noqa: BLE001 -- a failed side leg must not take the headline line with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    out["seconds"] = time.perf_counter() - t_begin
+    out["note"] = ("side legs after the headline's timed region, one fresh context each, one mrt_redraw per step, stream RNG; "
+                   "`value` above stays the headline's")
+    return out
+
+
 def tests_per_launch(hits, steps, world, n_spheres):
     """What the reference's linear scan (shader.wgsl:314-329: one sphere test per sphere per world_hit) executes per launch."""
     return hits / steps / world * n_spheres if steps else 0.0
@@ -235,6 +315,13 @@ def main():
                          "counter-based RNG: an EXTENSION with different images, never a headline line; it keeps the pixel-starved 1/8 "
                          "shares of an 8-GPU C5 run busy, DESIGN.md 4 / 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--schedule", default="hint", choices=["hint", "measure"],
+                    help="hint (default): pin the launch schedule profiles/schedules.json holds for this workload, if any "
+                         "(mrt_set_schedule_hint); measure: let the library's controller find it -- either way the run warms up until "
+                         "the schedule is final, and the line says which and what it was")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1 headline run: skip the side legs after the timed region that put C1, C2, C4, C5 and C5's 1/8 share into "
+                         "the line (other_configs)")
     ap.add_argument("--no-abi-legs", action="store_true",
                     help="N > 1: skip the two non-fatal legs after the timed run that drive the C ABI's own gathers (mrt_gather_rccl on a "
                          "communicator made here; native_runner --gpus N in one process), reported as abi_rccl_gather / abi_single_process")
@@ -255,7 +342,7 @@ def main():
     os.dup2(2, 1)
 
     # (before anything initialises HIP: up to 8 frames of a pixel-starved shard run side by side, each needs a hardware queue)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -315,6 +402,11 @@ def main():
         st.set_camera(cam)
     if a.rng == "counter":
         st.set_rng_mode(1)
+    schedules = load_schedules()
+    sched_key = f"{a.config}_n{world}"
+    pinned = schedules.get(sched_key) if (a.schedule == "hint" and headline and a.frames_per_step == 1) else None
+    if pinned:
+        st.set_schedule_hint(int(pinned["div"]), int(pinned["mult"]))
     sweep_variant = st.debug_sweep_variant() or 1
     _, _, lrows, _ = st.shard_info()
     gather_device = device if backend == "nccl" else torch.device("cpu")
@@ -363,6 +455,30 @@ def main():
     for _ in range(a.warmup - (1 if done_first else 0)):
         step()
     fence()
+    # The launch schedule must be final before the clock starts: the library's controller measures its way to it over the first
+    # frames (a trial = a sync of everything in flight and a different launch width), and a decision inside the timed steps would
+    # make the line depend on it.  Untimed steps beyond --warmup, until every rank's schedule is final (or a cap), reported as
+    # `settle_frames`; a pinned schedule is final from the first frame.  With N > 1 all ranks then take rank 0's.
+    def all_settled(mine):
+        if not use_dist:
+            return bool(mine)
+        flag = torch.tensor([1.0 if mine else 0.0], dtype=torch.float64, device=gather_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
+    settle_frames = 0
+    if a.frames_per_step == 1 and a.steps > 0:
+        settle_frames = settle(st, step, fence, all_settled, 600, 30.0)
+        if use_dist:
+            box = [st.get_schedule()]
+            dist.broadcast_object_list(box, src=0)
+            mine = st.get_schedule()
+            if box[0]["div"] and ((box[0]["div"], box[0]["mult"]) != (mine["div"], mine["mult"]) or not mine["settled"]):
+                st.set_schedule_hint(box[0]["div"], box[0]["mult"])
+                for _ in range(box[0]["frames_in_flight"]):
+                    step()
+                settle_frames += box[0]["frames_in_flight"]
+            fence()
+    schedule_before = st.get_schedule()
     c0 = st.read_counters()
     fence()
     t0 = time.perf_counter()
@@ -371,6 +487,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     c1 = st.read_counters()
+    schedule_after = st.get_schedule()
     kernel_ms = st.kernel_ms_history(min(a.steps, 64))
     # multi-GPU numbers with and without the gather -- a second, separately timed run of the same
     # K steps that only renders (reported as render_only_*, never as `value`)
@@ -499,6 +616,15 @@ def main():
             "rccl_world_size": dist.get_world_size() if use_dist else 1, "backend": backend if use_dist else None,
             "ranks": rank_devices,
             "scene_upload_ms": st.last_set_world_ms(),
+            # what the timed steps were scheduled with (mrt_get_schedule: a frame's kernel on 1 / div of the persistent waves,
+            # max(2, div) x mult frames in flight)
+            "schedule": {"div": schedule_after["div"], "mult": schedule_after["mult"], "final": schedule_after["settled"],
+                         "frames_in_flight": schedule_after["frames_in_flight"],
+                         "source": (f"pinned: profiles/schedules.json[{sched_key}]" if pinned else
+                                    "measured by the library's controller during the untimed steps"),
+                         "settle_frames": settle_frames,
+                         "changed_during_timed_steps": (schedule_before["div"], schedule_before["mult"]) != (schedule_after["div"], schedule_after["mult"]),
+                         "max_concurrent_frames": schedule_after["max_concurrent_frames"] or None},
             # north_star's roofline: HBM.  `achieved` / `frac` = algorithmic bytes of one launch over the WALL time per step (two
             # frames are in flight, so a launch's own duration -- kernel_ms, HIP events on its stream -- spans about two steps;
             # the per-launch figures are kept beside it).  Tiny by construction: 0.06 byte per sample; see valu_issue.
@@ -565,6 +691,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spheres, cam, width, height, a.depth, seed)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and not use_dist and headline and a.config == "c3" and not a.no_other_configs and a.steps > 0:
+            out["other_configs"] = other_config_rates(M, schedules if a.schedule == "hint" else {}, 75.0)
 
     # ---- N > 1: the C ABI's own gathers on the same workload, after everything that is timed for `value`.  Non-fatal by
     # construction: any exception becomes {"error": ...}.  A HANG (a collective or a peer copy that never completes -- these

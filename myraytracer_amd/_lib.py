@@ -13,7 +13,7 @@ import sys
 # run side by side on hardware queues of their own, and HIP's default is 4 per process.  Read by the runtime when it
 # initialises -- set here, at import, before anything (torch included) has made a HIP call.  Never overrides the caller's value.
 # (The C library itself never touches the environment: it measures what it got and holds its schedule to that.)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRT_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libmyraytracer_amd.so")

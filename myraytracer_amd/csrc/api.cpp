@@ -1235,13 +1235,15 @@ static int probe_max_slots(mrt_ctx* c) {
     float conc = 0.0f;
     MRT_TRY(probe_stream_concurrency(c, mrt_ctx::kMaxFrameSlots, &conc));
     c->slots_probed = true;
+    // (15 of 16 is what GPU_MAX_HW_QUEUES=16 gives -- the context's own stream holds a queue too: two of the sixteen frames
+    // then take turns, which over-subscription does not mind)
     uint32_t cap = mrt_ctx::kMaxFrameSlots;
-    while (cap > 2u && conc < (float)cap) cap /= 2u;
+    while (cap > 2u && conc < 0.75f * (float)cap) cap /= 2u;
     c->max_slots = cap;
     if (cap < mrt_ctx::kMaxFrameSlots) {
         char buf[256];
         std::snprintf(buf, sizeof buf, "myraytracer_amd: only %.0f of %u side streams run at a time in this process: at most %u frames in flight "
-                      "(set GPU_MAX_HW_QUEUES=16 before the process' first HIP call: INTEGRATION.md 2a)", conc, mrt_ctx::kMaxFrameSlots, cap);
+                      "(set GPU_MAX_HW_QUEUES=32 before the process' first HIP call: INTEGRATION.md 2a)", conc, mrt_ctx::kMaxFrameSlots, cap);
         g_err = buf;
         static const bool trace = std::getenv("MRT_TRACE_WIDTH") != nullptr;
         if (trace) std::fprintf(stderr, "%s\n", buf);
@@ -1313,7 +1315,22 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
         if (!c->stat_last.valid || st.seq > c->stat_last.seq) c->stat_last = st;
     }
     (void)hipGetLastError();        // (hipEventQuery's hipErrorNotReady is not an error)
-    *frames_running = running;
+    // How many frames the CALLER keeps in flight: the most seen still queued or running over the last (frames in flight) calls
+    // -- not this call's count alone, which dips whenever a convoy of frames has just ended (launched a little wider, the next
+    // frame then holds more of the chip and the dips feed on themselves: C5's 1/8 share 3,066 -> 2,840 Msamples/s), and which is
+    // 0, 1, 2, ... while a burst of calls fills an empty pipeline.  A new setting starts from "the caller keeps them all in
+    // flight"; a caller that waits for every frame is known for one after that many calls.
+    {
+        const uint32_t window = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots);
+        if (c->running_seen_n != window) {          // (a new setting, or the first call)
+            c->running_seen_n = window;
+            for (uint32_t i = 0; i < window; i++) c->running_seen[i] = window - 1u;
+        }
+        c->running_seen[c->frame_seq % window] = running;
+        uint32_t most = 0;
+        for (uint32_t i = 0; i < window; i++) most = std::max(most, c->running_seen[i]);
+        *frames_running = most;
+    }
     // A measurement window: from the first frame launched at the current setting with the pipeline full, over
     // 2 x (frames in flight) + 2 frames -- their lane utilisation (the samples above) and, the calls being paced by
     // the completions (the back-pressure above), their rate on the host's clock -- and over at least 20 ms: frames of a
@@ -1349,9 +1366,9 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
             mrt::width_policy_start(c->width, w);
             width_restart_measurement(c);
         }
-        *frames_running = 0;            // (the probe waited for everything)
+        c->running_seen_n = 0;
     }
-    *want = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots);
+    *want = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots);
     return MRT_OK;
 }
 
@@ -1821,7 +1838,7 @@ int mrt_set_wait_timeout(mrt_ctx* c, double seconds) {
 int mrt_get_schedule(mrt_ctx* c, uint32_t out[6]) {
     if (!c || !out) return MRT_ERR_INVALID_ARG;
     out[0] = c->width.div; out[1] = c->width.mult; out[2] = c->width.settled;
-    out[3] = c->width.div ? mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots) : c->frame_slots;
+    out[3] = c->width.div ? mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots) : c->frame_slots;
     out[4] = c->last_launch_div;
     out[5] = c->slots_probed ? c->max_slots : 0u;        // 0 = not measured yet (no setting has asked for more than two frames)
     return MRT_OK;
@@ -1832,8 +1849,8 @@ int mrt_set_schedule_hint(mrt_ctx* c, uint32_t div, uint32_t mult) {
     if (div == 0 && mult == 0) {
         c->hint_div = c->hint_mult = 0;
     } else {
-        if (div < 1 || div > mrt_ctx::kMaxFrameSlots || mult < 1 || mult > 4 || std::max(2u, div) * mult > mrt_ctx::kMaxFrameSlots)
-            return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_schedule_hint: div %u x mult %u (div 1..8, mult 1..4, max(2, div) x mult <= 8)", div, mult);
+        if (div < 1 || div > mrt::kMaxWidthDiv || mult < 1 || mult > 8 || std::max(2u, div) * mult > mrt_ctx::kMaxFrameSlots)
+            return fail(c, MRT_ERR_INVALID_ARG, "mrt_set_schedule_hint: div %u x mult %u (div 1..8, mult 1..8, max(2, div) x mult <= 16)", div, mult);
         c->hint_div = div; c->hint_mult = mult;
     }
     c->width.div = 0;                   // the next redraw takes the hint (or starts measuring again)

@@ -71,7 +71,7 @@ struct mrt_ctx {
     // C5) is different: its launch is as long as its heaviest pixel's chain while most of its waves end much earlier, and a
     // wave instruction costs the same with 40 % of its lanes active as with all -- so it runs more frames at once, each on
     // fewer, better packed waves (redraw_frames; round 4).  frame_slots is the count in use, slot[] the capacity.
-    static constexpr uint32_t kMaxFrameSlots = 8;
+    static constexpr uint32_t kMaxFrameSlots = 16;
     uint32_t frame_slots = 2;
     uint32_t last_slot = 0;                         // the slot of the most recent redraw
     int frame_slots_override = 0;                   // mrt_debug_set_frames_in_flight: 0 = automatic
@@ -108,6 +108,7 @@ struct mrt_ctx {
     uint32_t max_slots = kMaxFrameSlots;            // frames that can really run side by side (probe_stream_concurrency)
     bool slots_probed = false;
     uint32_t last_launch_div = 1, last_frames_running = 0;   // mrt_get_schedule: what the most recent launch was issued with
+    uint32_t running_seen[kMaxFrameSlots] = {}, running_seen_n = 0;    // frames seen queued or running at the last calls (schedule_frame)
     // settled settings by workload, so that a change of camera / samples per frame / scene and back does not start the trials
     // over (and a viewer that moves its camera every frame still reaches one)
     struct WidthMemo { uint32_t n_tiles, spp, large, counter, n_spheres, div, mult; };

@@ -16,10 +16,13 @@ struct WidthWorkload {
     uint32_t n_tiles;       // 8x8 tiles of the (shard of the) frame
     uint32_t n_waves;       // persistent waves of a full-width launch
     uint32_t max_slots;     // most frames that can be in flight (mrt_ctx::kMaxFrameSlots, capped by the hardware queues)
+                            // (a launch is never narrower than 1 / kMaxWidthDiv, whatever max_slots)
     uint32_t spp;           // samples per pixel and frame
     uint32_t n_members;     // member slots of the scene's hierarchy (> 1,024: the large-scene kernels)
     uint32_t counter;       // counter-RNG mode
 };
+
+constexpr uint32_t kMaxWidthDiv = 8;    // the narrowest launch: an eighth of the persistent waves
 
 struct WidthState {
     uint32_t div = 0, mult = 1;             // div 0 = not chosen yet for the current workload
@@ -43,20 +46,24 @@ inline uint32_t width_frames_in_flight(uint32_t div, uint32_t mult, uint32_t max
 // What is known up front.
 //  * A pixel-starved launch of long chains (fewer than two pixels per lane the chip holds, one sequential chain of >= 64
 //    samples each: an 8-GPU share of C5) lasts as long as its heaviest pixel while most of its waves are done far earlier, and
-//    a wave's iteration takes the same time at 1 to 4 waves per SIMD: as many frames at a time as there are slots, each on that
-//    share of the waves (C5's 1/8 share, one mrt_redraw per frame: 885 Msamples/s at 0.41 lane utilisation with 2 frames in
-//    flight on all waves -> 2,490 at 0.88 with 8).
+//    a wave's iteration takes the same time at 1 to 4 waves per SIMD: eight frames at a time, each on an eighth of the waves
+//    (C5's 1/8 share, one mrt_redraw per frame: 885 Msamples/s at 0.41 lane utilisation with 2 frames in flight on all waves
+//    -> 3,090 at 0.92 with 8) -- and, where the process has the hardware queues, eight MORE queued behind them: frames end out
+//    of order, a frame slot is reused only when ITS frame has ended, and between a launch's end and the next launch on its
+//    slot a sixth of the chip's wave slots stood empty (profiles/r05_shard_occupancy.txt); with twice the launches the chip
+//    holds, every workgroup that ends is replaced at once by one that waits (3,090 -> 3,705).
 //  * Chains of a few bounces (the reference's default: ONE sample per frame): a frame is bound by its longest path -- up to
 //    ray_depth wave-iterations in sequence -- not by throughput, and every iteration is shorter with fewer resident waves: a
 //    quarter of the waves, four frames side by side.
 //  * Large scenes: a half (their pixels' chains differ 10 x; every large scene measured gains or stays within 1 %).
 inline void width_policy_start(WidthState& s, const WidthWorkload& w) {
-    const uint32_t slots = width_max_u32(w.max_slots, 2u);
-    const bool starved = !w.counter && w.spp >= 64u && (uint64_t)w.n_tiles < 2ull * w.n_waves && w.n_tiles > w.n_waves / slots;
+    const uint32_t slots = width_max_u32(w.max_slots, 2u), narrowest = width_min_u32(kMaxWidthDiv, slots);
+    const bool starved = !w.counter && w.spp >= 64u && (uint64_t)w.n_tiles < 2ull * w.n_waves && w.n_tiles > w.n_waves / narrowest;
     const bool short_chains = w.spp < 4u && (uint64_t)w.n_tiles * 4u >= 2ull * w.n_waves;
     s = WidthState();
-    s.div = starved ? slots : short_chains ? width_min_u32(4u, slots)
+    s.div = starved ? narrowest : short_chains ? width_min_u32(4u, slots)
           : (!w.counter && w.n_members > 1024u && w.n_tiles >= 4u * w.n_waves) ? 2u : 1u;
+    if (starved && slots >= 2u * narrowest) s.mult = 2u;
 }
 
 // A window has closed: ends a running trial (kept only if the rate rose by 3 %, else the previous setting returns and stays),
@@ -73,7 +80,7 @@ inline void width_policy_step(WidthState& s, const WidthWorkload& w, const Width
     if (!s.settled) {
         const uint32_t in_flight = width_max_u32(2u, s.div) * s.mult;
         const uint32_t cand = s.div == 1u ? 4u : s.div * 2u;
-        const bool can_narrow = cand <= w.max_slots && (uint64_t)w.n_tiles * cand >= 2ull * w.n_waves && w.n_waves >= cand;
+        const bool can_narrow = cand <= width_min_u32(kMaxWidthDiv, w.max_slots) && (uint64_t)w.n_tiles * cand >= 2ull * w.n_waves && w.n_waves >= cand;
         const bool can_add = in_flight * 2u <= w.max_slots;
         if (m.util >= 0.90 && m.util < 0.95 && (can_narrow || can_add) && ++s.low_windows < 2u) {
             // measure again at the same setting

@@ -19,11 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_forced_schedule_transitions_mid_accumulation_are_bit_identical(mrt, oracle):
     """12 frames of the cover scene, the schedule changed under the accumulation: full width -> a quarter (4 frames in flight)
-    -> an eighth (8) -> a half (2) -> twice the frames at a half (4) -> back; every change waits for the frames under way and
+    -> an eighth (8, then 16 over-subscribed) -> a half (2) -> twice the frames at a half (4) -> back; every change waits for the frames under way and
     re-allocates slots (api.cpp, set_frame_slots).  The accumulated image must be the one 12 serial frames give, and the oracle's."""
     spheres, cam = mrt.scene_cover(1, True)
     w, h, spp, depth, frames = 192, 104, 6, 50, 12
-    plan = [(1, 1), (1, 1), (4, 1), (4, 1), (8, 1), (8, 1), (8, 1), (2, 1), (2, 1), (2, 2), (2, 2), (2, 1)]
+    plan = [(1, 1), (1, 1), (4, 1), (4, 1), (8, 1), (8, 1), (8, 2), (2, 1), (2, 1), (2, 2), (2, 2), (2, 1)]
     assert len(plan) == frames
     args = mrt.Args(w, h, spp, depth, 1.0)
     with mrt.State(args, seed=11) as st:
@@ -59,12 +59,15 @@ def test_schedule_hint_is_validated_and_released(mrt):
     spheres, cam = mrt.scene_cover(1, True)
     with mrt.State(mrt.Args(64, 40, 4, 8, 1.0), seed=3) as st:
         st.set_world(spheres); st.set_camera(cam)
-        for bad in ((0, 1), (9, 1), (8, 2), (1, 5), (3, 4)):
+        for bad in ((0, 1), (9, 1), (8, 3), (1, 9), (3, 8)):
             with pytest.raises(mrt.MrtError):
                 st.set_schedule_hint(*bad)
         st.set_schedule_hint(4, 2)
         st.redraw()
         assert st.get_schedule()["frames_in_flight"] == 8
+        st.set_schedule_hint(8, 2)                       # twice the launches the chip holds
+        st.redraw()
+        assert st.get_schedule()["frames_in_flight"] == 16
         st.set_schedule_hint(0, 0)                       # back to the measured setting
         st.redraw()
         sch = st.get_schedule()
@@ -73,23 +76,25 @@ def test_schedule_hint_is_validated_and_released(mrt):
 
 def test_a_caller_that_waits_for_every_frame_gets_the_whole_chip(mrt):
     """The setting says an eighth of the waves per launch, eight frames in flight; a caller that reads every frame back keeps
-    ONE in flight and must not be run on an eighth of the chip (width_policy.h, width_launch_div).  A caller that issues its
-    frames in a burst gets the narrow launches."""
+    ONE in flight and must not be run on an eighth of the chip for long (width_policy.h, width_launch_div: a launch is never
+    narrower than the most frames seen in flight over the last calls; a new setting assumes a full pipeline for that many
+    calls).  A caller that issues its frames in bursts gets the narrow launches back."""
     spheres, cam = mrt.scene_cover(1, True)
     with mrt.State(mrt.Args(640, 360, 64, 50, 1.0), seed=5) as st:
         st.set_world(spheres); st.set_camera(cam)
         st.set_schedule_hint(8, 1)
-        for _ in range(4):
+        shares = []
+        for _ in range(12):
             st.redraw()
             st.read_framebuffer()
-            assert st.get_schedule()["last_launch_div"] == 1
+            shares.append(st.get_schedule()["last_launch_div"])
+        assert shares[0] == 8 and shares[-3:] == [1, 1, 1], shares
         shares = []
-        for _ in range(16):
+        for _ in range(32):
             st.redraw()
             shares.append(st.get_schedule()["last_launch_div"])
         st.sync()
         assert max(shares) >= 4, shares
-        assert shares[0] == 1                            # the first frame of a burst starts on an empty chip
 
 
 def test_a_stalled_wait_is_a_loud_status_not_a_hang(mrt):
@@ -122,13 +127,16 @@ def test_a_stalled_wait_is_a_loud_status_not_a_hang(mrt):
 
 
 def test_stream_concurrency_probe_sees_the_hardware_queues(mrt):
-    """The package sets GPU_MAX_HW_QUEUES=16 before the first HIP call (unless the caller set it): eight side streams then run
-    side by side, and a pixel-starved workload gets its eight frames in flight."""
-    if os.environ.get("GPU_MAX_HW_QUEUES") not in ("16",):
+    """The package sets GPU_MAX_HW_QUEUES=32 before the first HIP call (unless the caller set it): sixteen side streams then run
+    side by side, and a pixel-starved workload gets its sixteen frames in flight."""
+    if os.environ.get("GPU_MAX_HW_QUEUES") not in ("32",):
         pytest.skip("GPU_MAX_HW_QUEUES was set by the caller")
+    # (streams are dealt onto the hardware queues round-robin, counting every stream the process has ever made: in a
+    # long-lived process two of a context's streams may share one, so "nearly all", not "all")
     with mrt.State(mrt.Args(64, 40, 2, 8, 1.0), seed=1) as st:
-        conc = st.debug_stream_concurrency(8)
-    assert conc >= 6.0, conc
+        assert st.debug_stream_concurrency(8) >= 6.0
+        conc = st.debug_stream_concurrency(16)
+    assert conc >= 12.0, conc
 
 
 _FOUR_QUEUES = r"""
@@ -141,7 +149,7 @@ with M.State(M.Args(1920, 1080, 64, 4, 1.0), seed=1, shard=(0, 8)) as st:      #
     st.set_world(sp); st.set_camera(cam)
     st.redraw(); st.sync()
     sch = st.get_schedule()
-    conc = st.debug_stream_concurrency(8)
+    conc = st.debug_stream_concurrency(16)
 warn = M._lib.load().mrt_last_error(None).decode()
 print(sch["max_concurrent_frames"], sch["frames_in_flight"], round(conc, 2), "|", warn)
 """

@@ -41,6 +41,28 @@ def test_a_process_with_four_hardware_queues_starts_within_them(mrt):
     assert start(mrt, two)[:2] == [2, 1]
 
 
+def test_with_sixteen_queues_a_starved_share_is_over_subscribed(mrt):
+    """Frames end out of order and a slot is reused only when ITS frame has ended: with eight launches for eight eighths of the
+    chip a sixth of the wave slots stood empty between a launch's end and the next on its slot.  Where the process can run
+    sixteen streams, a starved share starts with eight more launches queued behind the eight that fit."""
+    sixteen = C5_EIGHTH[:2] + (16,) + C5_EIGHTH[3:]
+    s = start(mrt, sixteen)
+    assert s[:2] == [8, 2]                                   # never narrower than an eighth
+    s = step(mrt, sixteen, s, 0.80, 50.0)
+    assert s[:2] == [8, 2] and s[SETTLED] == 1               # no room left: 16 in flight is the most there is
+    # a workload that fills the chip is not touched by the extra slots
+    c3 = C3[:2] + (16,) + C3[3:]
+    assert start(mrt, c3)[:2] == [1, 1]
+    s = step(mrt, c3, start(mrt, c3), 0.85, 12.0)
+    assert s[:2] == [4, 1]
+    s = step(mrt, c3, s, 0.90, 13.0)                         # kept (+ 8 %); the next trial narrows to an eighth, not beyond
+    s = step(mrt, c3, s, 0.90, 13.0)
+    assert s[:2] == [8, 1] and s[PREV_DIV] == 4
+    s = step(mrt, c3, s, 0.90, 14.0)                         # kept; an eighth is the narrowest launch: twice the frames instead
+    s = step(mrt, c3, s, 0.90, 14.0)
+    assert s[:2] == [8, 2] and s[PREV_DIV] == 8 and s[PREV_MULT] == 1
+
+
 def test_high_utilisation_settles_at_once(mrt):
     s = step(mrt, C3, start(mrt, C3), 0.97, 12.0)
     assert s[:2] == [1, 1] and s[SETTLED] == 1 and s[PREV_DIV] == 0
