@@ -13,7 +13,7 @@ CLI      := $(LIBDIR)/native_runner
 # every value would cost a v_accvgpr_read first.
 HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -fno-vectorize -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form -Wall -Wextra -Wno-unused-parameter
 SRCS     := $(CSRC)/kernels.hip $(CSRC)/tile_order.hip $(CSRC)/debug_kernels.hip $(CSRC)/api.cpp $(CSRC)/multi_gpu.cpp $(CSRC)/scenes.cpp $(CSRC)/image_io.cpp
-HDRS     := $(CSRC)/mrt_internal.h $(CSRC)/mrt_ctx.h $(CSRC)/mrt_device.h include/myraytracer_amd.h include/myraytracer_amd_debug.h
+HDRS     := $(CSRC)/mrt_internal.h $(CSRC)/mrt_ctx.h $(CSRC)/mrt_device.h $(CSRC)/width_policy.h include/myraytracer_amd.h include/myraytracer_amd_debug.h
 
 all: $(LIB) $(CLI) oracle
 

@@ -206,8 +206,8 @@ int mrt_read_seeds(mrt_ctx* ctx, uint32_t* out, size_t cap_u32);    /* this shar
 /* State::redraw (lib.rs:241-307) minus the present pass: one raytrace pass of
  * samples_per_frame spp into framebuffers.target blended with .secondary, swap,
  * sample_count += 1, framebuffer_weight = min(max_w, n/(n+1)), new rng_shuffle, Locals
- * update.  Asynchronous on the ctx's stream, like a swap chain: consecutive frames overlap on the GPU (2 in flight; up to 8 for a
- * shard with too few pixels to fill the chip, see mrt_get_schedule), and the call returns at once unless that many frames
+ * update.  Asynchronous on the ctx's stream, like a swap chain: consecutive frames overlap on the GPU (2 to 16 in flight,
+ * see mrt_get_schedule), and the call returns at once unless that many frames
  * are already queued.
  * BACK-PRESSURE: in that case the call blocks the HOST (polling, with the deadline of mrt_set_wait_timeout) until the render
  * kernel of the oldest frame in flight has completed.  That kernel runs on a side stream of the library and waits only for
@@ -217,14 +217,15 @@ int mrt_read_seeds(mrt_ctx* ctx, uint32_t* out, size_t cap_u32);    /* this shar
  * The next call's blend is ordered behind this one's on the ctx's stream. */
 int mrt_redraw(mrt_ctx* ctx);
 /* The launch schedule (no reference counterpart: lib.rs:241-307 has one frame after the other).  A frame's render kernel runs
- * on 1 / div of the persistent waves the chip holds and max(2, div) x mult frames are in flight; the library measures its way
- * to a setting over the first frames of a workload.  mrt_get_schedule: out[0] = div, out[1] = mult, out[2] = 1
+ * on 1 / div of the persistent waves the chip holds and max(2, div) x mult frames are in flight -- with mult 2, twice the
+ * launches the chip holds: frames end out of order, and a queued launch takes every workgroup slot the moment it frees; the
+ * library measures its way to a setting over the first frames of a workload.  mrt_get_schedule: out[0] = div, out[1] = mult, out[2] = 1
  * once the setting is final for the current workload (or pinned), out[3] = frames in flight, out[4] = the share the most recent
  * launch really got (1 / out[4]: never narrower than the frames the caller really keeps in flight), out[5] = frames that can run
- * side by side in this process (hardware queues: GPU_MAX_HW_QUEUES).
+ * side by side in this process (hardware queues: GPU_MAX_HW_QUEUES; 0 = not measured yet).
  * mrt_set_schedule_hint pins (div, mult) -- e.g. what an earlier run of the same workload settled at, or rank 0's setting on
  * every rank of a multi-GPU run -- so that no trial runs and two runs schedule alike; (0, 0) returns to the measured
- * setting.  div 1..8, mult 1..4, max(2, div) x mult <= 8.  Takes effect at the next redraw (a change waits for the frames
+ * setting.  div 1..8, mult 1..8, max(2, div) x mult <= 16.  Takes effect at the next redraw (a change waits for the frames
  * under way); the images are the same whatever the schedule. */
 int mrt_get_schedule(mrt_ctx* ctx, uint32_t out[6]);
 int mrt_set_schedule_hint(mrt_ctx* ctx, uint32_t div, uint32_t mult);
