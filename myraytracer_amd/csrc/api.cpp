@@ -1243,7 +1243,7 @@ static int probe_max_slots(mrt_ctx* c) {
     if (cap < mrt_ctx::kMaxFrameSlots) {
         char buf[256];
         std::snprintf(buf, sizeof buf, "myraytracer_amd: only %.0f of %u side streams run at a time in this process: at most %u frames in flight "
-                      "(set GPU_MAX_HW_QUEUES=32 before the process' first HIP call: INTEGRATION.md 2a)", conc, mrt_ctx::kMaxFrameSlots, cap);
+                      "(set GPU_MAX_HW_QUEUES=16 before the process' first HIP call: INTEGRATION.md 2a)", conc, mrt_ctx::kMaxFrameSlots, cap);
         g_err = buf;
         static const bool trace = std::getenv("MRT_TRACE_WIDTH") != nullptr;
         if (trace) std::fprintf(stderr, "%s\n", buf);
@@ -1857,7 +1857,7 @@ int mrt_set_schedule_hint(mrt_ctx* c, uint32_t div, uint32_t mult) {
     return MRT_OK;
 }
 
-int mrt_debug_width_policy(int op, const uint32_t workload[6], uint32_t state[7], double util, double rate) {
+int mrt_debug_width_policy(int op, const uint32_t workload[6], uint32_t state[8], double util, double rate) {
     if (!workload || !state || op < 0 || op > 2) return MRT_ERR_INVALID_ARG;
     mrt::WidthWorkload w;
     w.n_tiles = workload[0]; w.n_waves = workload[1]; w.max_slots = workload[2]; w.spp = workload[3]; w.n_members = workload[4]; w.counter = workload[5];
@@ -1865,12 +1865,14 @@ int mrt_debug_width_policy(int op, const uint32_t workload[6], uint32_t state[7]
     float pr;
     std::memcpy(&pr, &state[6], 4);
     s.div = state[0]; s.mult = state[1]; s.prev_div = state[2]; s.prev_mult = state[3]; s.low_windows = state[4]; s.settled = state[5]; s.prev_rate = pr;
+    s.explored = state[7];
     if (op == 0) mrt::width_policy_start(s, w);
     else if (op == 1) { mrt::WidthWindow m; m.util = util; m.rate = rate; mrt::width_policy_step(s, w, m); }
     else { state[0] = mrt::width_launch_div(s.div, (uint32_t)util); return MRT_OK; }
     pr = (float)s.prev_rate;
     state[0] = s.div; state[1] = s.mult; state[2] = s.prev_div; state[3] = s.prev_mult; state[4] = s.low_windows; state[5] = s.settled;
     std::memcpy(&state[6], &pr, 4);
+    state[7] = s.explored;
     return MRT_OK;
 }
 
