@@ -71,7 +71,7 @@ def launch_ranks(n, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-               GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "16"))      # frames in flight of pixel-starved shards (api.cpp)
+               GPU_MAX_HW_QUEUES=os.environ.get("GPU_MAX_HW_QUEUES", "20"))      # frames in flight of pixel-starved shards (api.cpp)
     return subprocess.run(cmd, env=env).returncode
 
 
@@ -342,7 +342,7 @@ def main():
     os.dup2(2, 1)
 
     # (before anything initialises HIP: up to 8 frames of a pixel-starved shard run side by side, each needs a hardware queue)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
     import numpy as np
     import torch
     import torch.distributed as dist

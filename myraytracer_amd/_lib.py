@@ -13,11 +13,12 @@ import sys
 # run side by side on hardware queues of their own, and HIP's default is 4 per process.  Read by the runtime when it
 # initialises -- set here, at import, before anything (torch included) has made a HIP call.  Never overrides the caller's value.
 # (The C library itself never touches the environment: it measures what it got and holds its schedule to that.)
-# Sixteen, not more: once a process has created some 24 hardware queues, EVERY kernel of it runs slower -- measured, round 5
-# (scripts/queue_oversubscription.py): C2 13,400 Msamples/s with up to 16 queues, 12,000 with 24, 9,060 with 32, and closing the
-# streams does not bring it back.  With sixteen queues for the library's up to 16 + 1 streams two frames share one, which a
-# schedule of twice the launches the chip holds does not mind.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Twenty: enough for the library's up to 16 side streams + the context's own + the null stream to have a queue each (with 16,
+# two of sixteen frames in flight take turns on one queue: C5's 1/8 share 2,790 instead of 3,750 Msamples/s) -- and not more:
+# once a process has created some 24 hardware queues, EVERY kernel of it runs slower, for good -- measured, round 5
+# (scripts/queue_oversubscription.py, profiles/r05_queue_oversubscription.txt): C2 13,400 Msamples/s with up to 22 queues,
+# 12,000 with 24, 9,060 with 32, and closing the streams does not bring it back.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRT_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libmyraytracer_amd.so")

@@ -1235,15 +1235,16 @@ static int probe_max_slots(mrt_ctx* c) {
     float conc = 0.0f;
     MRT_TRY(probe_stream_concurrency(c, mrt_ctx::kMaxFrameSlots, &conc));
     c->slots_probed = true;
-    // (15 of 16 is what GPU_MAX_HW_QUEUES=16 gives -- the context's own stream holds a queue too: two of the sixteen frames
-    // then take turns, which over-subscription does not mind)
+    // (all sixteen or eight: with 15 of 16 -- what GPU_MAX_HW_QUEUES=16 gives, the context's own stream holds a queue too -- two
+    // of the sixteen frames take turns on one queue, and C5's 1/8 share renders 2,790 Msamples/s instead of 3,750, less than
+    // with eight frames in flight)
     uint32_t cap = mrt_ctx::kMaxFrameSlots;
-    while (cap > 2u && conc < 0.75f * (float)cap) cap /= 2u;
+    while (cap > 2u && conc < (cap == 8u ? 7.0f : (float)cap)) cap /= 2u;
     c->max_slots = cap;
     if (cap < mrt_ctx::kMaxFrameSlots) {
         char buf[256];
         std::snprintf(buf, sizeof buf, "myraytracer_amd: only %.0f of %u side streams run at a time in this process: at most %u frames in flight "
-                      "(set GPU_MAX_HW_QUEUES=16 before the process' first HIP call: INTEGRATION.md 2a)", conc, mrt_ctx::kMaxFrameSlots, cap);
+                      "(set GPU_MAX_HW_QUEUES=20 before the process' first HIP call: INTEGRATION.md 2a)", conc, mrt_ctx::kMaxFrameSlots, cap);
         g_err = buf;
         static const bool trace = std::getenv("MRT_TRACE_WIDTH") != nullptr;
         if (trace) std::fprintf(stderr, "%s\n", buf);
@@ -1348,6 +1349,26 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
         mrt::WidthWindow m;
         m.util = (double)(c->stat_last.hits - c->stat_base.hits) / (double)(c->stat_last.slots - c->stat_base.slots);
         m.rate = (double)(c->frame_seq - c->width_t0_seq) / std::max(1e-9, std::chrono::duration<double>(now - c->width_t0).count());
+        // The frame rate, better: frames END in convoys (the launches that share the chip start together), so a count of the calls
+        // the completions let through over a window of a few convoys is off by up to a convoy -- 4 frames in 18, far beyond the
+        // 3 % a trial is judged by (the first cut of this round kept a quarter width for C3 that renders 8 % less).  Every frame
+        // slot is refilled the moment its frame ends (the back-pressure), so slots / (a slot's start-to-start time) is the rate
+        // (Little's law), and start-to-start times are whole frames on the DEVICE's clock: the start events of frame f and of
+        // frame f + slots, the next on the same slot, over the window's frames.
+        {
+            const uint32_t slots = c->frame_slots;
+            double sum_ms = 0.0;
+            uint32_t n = 0;
+            for (uint64_t f = c->width_t0_seq; f + slots < c->frame_seq; f++) {
+                if (c->frame_seq - f > mrt_ctx::kEventRing) continue;               // (overwritten since)
+                hipEvent_t a = c->ev_start[f % mrt_ctx::kEventRing], b = c->ev_start[(f + slots) % mrt_ctx::kEventRing];
+                if (hipEventQuery(b) != hipSuccess) break;                          // (not started yet, nor are the later ones)
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.0f) { sum_ms += ms; n++; }
+            }
+            (void)hipGetLastError();
+            if (n >= std::max(2u, slots / 2u)) m.rate = (double)slots * 1e3 * (double)n / sum_ms;     // (else: the host's count above)
+        }
         if (trace) std::fprintf(stderr, "mrt width: frame %llu: div %u x %u, window %llu frames, utilisation %.4f, %.2f frames/s%s\n",
                                 (unsigned long long)c->frame_seq, c->width.div, c->width.mult, (unsigned long long)(c->frame_seq - c->width_t0_seq),
                                 m.util, m.rate, c->width.prev_div != 0 ? " (trial)" : "");
@@ -1506,7 +1527,7 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
             p.tile_order = S.d_tile_order;
         }
     }
-    const uint32_t ev = (uint32_t)(c->timed_frames % mrt_ctx::kEventRing);
+    const uint32_t ev = (uint32_t)(c->frame_seq % mrt_ctx::kEventRing);       // (the ring is indexed by the frame: schedule_frame reads it back)
     if (c->d_wave_log) {            // diagnostic (mrt_debug_wave_log): the frame's own part of the ring, cleared (a narrow launch leaves most of it unwritten)
         p.wave_log = c->d_wave_log + (size_t)(c->frame_seq % mrt_ctx::kWaveLogFrames) * c->wave_log_waves * 4;
         HIP_TRY(c, hipMemsetAsync(p.wave_log, 0, c->wave_log_waves * 4 * sizeof(unsigned long long), S.stream));
@@ -1526,7 +1547,6 @@ static int redraw_frames(mrt_ctx* c, uint32_t batch, bool frames_in_lane = false
         S.stats_seq = c->frame_seq;
         S.stats_pending = true;
     }
-    c->timed_frames++;
     // caller's stream: blend into the accumulated framebuffer (shader.wgsl:383-385) once the render is done -- frame by frame
     HIP_TRY(c, hipStreamWaitEvent(c->stream, S.render_done, 0));
     for (uint32_t b = 0; b < batch; b++) {
@@ -2067,10 +2087,10 @@ int mrt_debug_wave_log(mrt_ctx* c, uint64_t* out, size_t cap_waves, size_t* n_wa
 int mrt_kernel_ms_history(mrt_ctx* c, float* ms, size_t cap, size_t* n_out) {
     if (!c || !ms || !n_out) return MRT_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    size_t n = c->timed_frames < mrt_ctx::kEventRing ? (size_t)c->timed_frames : mrt_ctx::kEventRing;
+    size_t n = c->frame_seq < mrt_ctx::kEventRing ? (size_t)c->frame_seq : mrt_ctx::kEventRing;
     if (n > cap) n = cap;
     for (size_t i = 0; i < n; i++) {          // ms[0] = oldest of the n most recent redraws
-        const uint32_t slot = (uint32_t)((c->timed_frames - n + i) % mrt_ctx::kEventRing);
+        const uint32_t slot = (uint32_t)((c->frame_seq - n + i) % mrt_ctx::kEventRing);
         MRT_TRY(mrt::wait_event(c, c->ev_stop[slot], "mrt_kernel_ms_history: the render kernel's stop event"));
         HIP_TRY(c, hipEventElapsedTime(&ms[i], c->ev_start[slot], c->ev_stop[slot]));
     }
@@ -2080,7 +2100,7 @@ int mrt_kernel_ms_history(mrt_ctx* c, float* ms, size_t cap, size_t* n_out) {
 
 int mrt_last_kernel_ms(mrt_ctx* c, float* ms) {
     if (!c || !ms) return MRT_ERR_INVALID_ARG;
-    if (!c->timed_frames) return fail(c, MRT_ERR_STATE, "mrt_last_kernel_ms: nothing rendered yet");
+    if (!c->frame_seq) return fail(c, MRT_ERR_STATE, "mrt_last_kernel_ms: nothing rendered yet");
     size_t n = 0;
     return mrt_kernel_ms_history(c, ms, 1, &n);
 }

@@ -144,10 +144,9 @@ struct mrt_ctx {
 
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    // ring of HIP event pairs around the render kernel of the most recent redraws
+    // ring of HIP event pairs around the render kernel of the most recent redraws, frame f at f % kEventRing
     static constexpr uint32_t kEventRing = 64;
     hipEvent_t ev_start[kEventRing] = {}, ev_stop[kEventRing] = {};
-    uint64_t timed_frames = 0;             // redraws recorded so far
 
     bool shuffle_overridden = false;       // mrt_set_rng_shuffle since the last frame
     bool batch_frames = true;              // mrt_render may render several frames per launch (mrt_debug_set_frame_batching)

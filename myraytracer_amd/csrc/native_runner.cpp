@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     // The HOST's job, before its first HIP call: up to eight frames of a pixel-starved shard run side by
     // side, each on a stream of its own, and HIP gives a process 4 hardware queues unless told otherwise.  The library itself
     // never touches the environment.  A value the user exported wins.
-    (void)setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    (void)setenv("GPU_MAX_HW_QUEUES", "20", 0);
     mrt_args args;
     mrt_args_default(&args);
     uint32_t frames = 1, warmup = 0, rng_mode = MRT_RNG_PIXEL_STREAM; uint64_t seed = 1; int device = 0;

@@ -40,7 +40,7 @@ for key, scene, w, h, spp, depth, shard in WORK:
             if cam is not None: st.set_camera(cam)
             st.set_draw_counting(False)
             n, t0 = 0, time.perf_counter()
-            while not st.get_schedule()["settled"] and n < 2000 and time.perf_counter() - t0 < 60.0:
+            while not st.get_schedule()["settled"] and n < 2000 and time.perf_counter() - t0 < 150.0:
                 st.redraw(); n += 1
             st.sync()
             sch = st.get_schedule()

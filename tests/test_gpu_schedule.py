@@ -127,9 +127,9 @@ def test_a_stalled_wait_is_a_loud_status_not_a_hang(mrt):
 
 
 def test_stream_concurrency_probe_sees_the_hardware_queues(mrt):
-    """The package sets GPU_MAX_HW_QUEUES=16 before the first HIP call (unless the caller set it): sixteen side streams then run
+    """The package sets GPU_MAX_HW_QUEUES=20 before the first HIP call (unless the caller set it): sixteen side streams then run
     side by side, and a pixel-starved workload gets its sixteen frames in flight."""
-    if os.environ.get("GPU_MAX_HW_QUEUES") not in ("16",):
+    if os.environ.get("GPU_MAX_HW_QUEUES") not in ("20",):
         pytest.skip("GPU_MAX_HW_QUEUES was set by the caller")
     # (streams are dealt onto the hardware queues round-robin, counting every stream the process has ever made: in a
     # long-lived process two of a context's streams may share one, so "nearly all", not "all")
