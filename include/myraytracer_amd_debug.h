@@ -121,11 +121,11 @@ int mrt_debug_lds_layout(uint32_t n_members, uint32_t n_nodes, uint32_t levels, 
  * pixel-starved shards.  A change waits for the frames under way.  The images are the same. */
 int mrt_debug_set_frames_in_flight(mrt_ctx* ctx, int slots);
 /* Host only, no GPU needed: the launch-width controller's policy (csrc/width_policy.h) on synthetic input, for its CPU unit
- * tests.  workload[6] = {n_tiles, n_waves, max_slots, spp, n_members, counter-RNG?}; state[8] in / out = {div, mult, prev_div,
- * prev_mult, low_windows, settled, prev_rate as the bits of an f32, explored}.  op 0: what is known up front (state out only);
+ * tests.  workload[6] = {n_tiles, n_waves, max_slots, spp, n_members, counter-RNG?}; state[7] in / out = {div, mult, prev_div,
+ * prev_mult, low_windows, settled, prev_rate as the bits of an f32}.  op 0: what is known up front (state out only);
  * op 1: one measurement window has closed with lane utilisation `util` and `rate` frames / s; op 2: state[0] out = the share a
  * launch gets under setting state[0] when `util` (as an integer) earlier frames are still queued or running. */
-int mrt_debug_width_policy(int op, const uint32_t workload[6], uint32_t state[8], double util, double rate);
+int mrt_debug_width_policy(int op, const uint32_t workload[6], uint32_t state[7], double util, double rate);
 /* Diagnostic: how many of `streams` (2..8) side streams of this context really run side by side in this process -- identical
  * short clock-bounded kernels, one per stream, each stamping its start and end on the device's clock: *out = the most of them
  * resident at one instant (hardware queues are shared round-robin: HIP's default of 4 per process gives 4).  What caps the

@@ -221,22 +221,20 @@ def write_image(path: str, rgba: np.ndarray):
 
 def width_policy(op: int, workload: Sequence[int], state: Sequence[int], util: float = 0.0, rate: float = 0.0):
     """The launch-width controller's policy (csrc/width_policy.h) on synthetic input; host only.  workload = (n_tiles, n_waves,
-    max_slots, spp, n_members, counter); state = (div, mult, prev_div, prev_mult, low_windows, settled, prev_rate, explored).  Returns
+    max_slots, spp, n_members, counter); state = (div, mult, prev_div, prev_mult, low_windows, settled, prev_rate).  Returns
     the new state (op 0: start, op 1: a window closed) or the launch share (op 2, util = frames still running)."""
     import struct
     L = _lib.load()
     w = (C.c_uint32 * 6)(*[int(x) for x in workload])
-    st = list(state) if state is not None else [0, 1, 0, 1, 0, 0, 0.0, 0]
-    if len(st) == 7:
-        st.append(0)
+    st = list(state) if state is not None else [0, 1, 0, 1, 0, 0, 0.0]
     bits = struct.unpack("<I", struct.pack("<f", float(st[6])))[0]
-    sv = (C.c_uint32 * 8)(*[int(x) for x in st[:6]], bits, int(st[7]))
+    sv = (C.c_uint32 * 7)(*[int(x) for x in st[:6]], bits)
     rc = L.mrt_debug_width_policy(op, w, sv, float(util), float(rate))
     if rc:
         raise MrtError(rc, "mrt_debug_width_policy")
     if op == 2:
         return int(sv[0])
-    return [int(sv[i]) for i in range(6)] + [struct.unpack("<f", struct.pack("<I", sv[6]))[0], int(sv[7])]
+    return [int(sv[i]) for i in range(6)] + [struct.unpack("<f", struct.pack("<I", sv[6]))[0]]
 
 
 # ------------------------------------------------------------------ State

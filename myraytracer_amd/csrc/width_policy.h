@@ -29,7 +29,6 @@ struct WidthState {
     uint32_t prev_div = 0, prev_mult = 1;   // prev_div != 0: a trial is running; what it would return to
     uint32_t low_windows = 0;               // consecutive windows between the two utilisation thresholds (a trial takes two)
     uint32_t settled = 0;                   // no further trials for this workload
-    uint32_t explored = 0;                  // the one trial a well-utilised setting gets has been spent
     double prev_rate = 0.0;                 // frames / s measured at (prev_div, prev_mult)
 };
 
@@ -76,11 +75,13 @@ inline void width_policy_start(WidthState& s, const WidthWorkload& w) {
 // A window has closed: ends a running trial (kept only if the rate rose by 3 %, else the previous setting returns and stays),
 // then decides whether another one starts.  Below 0.90 one window is evidence enough (a pixel-starved share reads 0.4 to 0.8);
 // between 0.90 and 0.95 a trial takes two consecutive windows (a window's utilisation scatters by a few per cent around the
-// workload's own -- C3: 0.93 to 1.02 around 0.970); with no room left the setting stays.  At 0.95 and above the next narrower
-// width gets ONE trial per workload all the same: lane utilisation does not see the wave slots that stand empty between
-// launches, and a narrower, over-subscribed schedule can still gain (C4's 1/8 share reads 0.96 at full width and renders 3 %
-// more on a quarter of the waves, eight in flight); a trial that does not pay costs a dozen frames at the slower setting.
+// workload's own -- C3: 0.93 to 1.02 around 0.970); at 0.95 and above, or with no room left, the setting stays.
 // Narrower only while a launch's waves still get at least two tiles each; else twice the frames in flight.
+// (Round 5 also gave every well-utilised setting ONE exploratory trial of the next narrower width -- C4's 1/8 share reads 0.96
+// at full width and renders 3 % more on a quarter of the waves, eight in flight.  Removed: a gain of 3 % cannot be told from
+// the transient after the change of setting within a few dozen frames -- C3 was "measured" 4 % faster at a quarter width, where
+// it renders 2 % less -- while the trials below decide on gains of 10 % and more.  Such settings are found offline instead:
+// scripts/settle_schedules.py --sweep, profiles/schedules.json, mrt_set_schedule_hint.)
 inline void width_policy_step(WidthState& s, const WidthWorkload& w, const WidthWindow& m) {
     uint32_t next_div = s.div, next_mult = s.mult;
     if (s.prev_div != 0u) {
@@ -100,14 +101,6 @@ inline void width_policy_step(WidthState& s, const WidthWorkload& w, const Width
             s.prev_mult = s.mult;
             s.prev_rate = m.rate;
             if (can_narrow) { next_div = cand; next_mult = width_mult_for(cand, w.max_slots); } else next_mult = s.mult * 2u;
-        } else if (can_narrow && !s.explored) {
-            s.explored = 1u;
-            s.low_windows = 0u;
-            s.prev_div = s.div;
-            s.prev_mult = s.mult;
-            s.prev_rate = m.rate;
-            next_div = cand;
-            next_mult = width_mult_for(cand, w.max_slots);
         } else {
             s.settled = 1u;
         }
