@@ -217,11 +217,14 @@ def load_schedules():
         return {}
 
 
-def settle(st, step, fence, all_settled, max_frames, max_seconds):
-    """Run untimed steps until the launch schedule is final for this workload (every rank's), or the cap.  Returns the steps run."""
+def settle(st, step, fence, all_settled, max_frames, max_seconds, done=0):
+    """Run untimed steps until the launch schedule is final for this workload (every rank's) AND three generations of frames
+    (3 x the frames in flight, `done` of them rendered already) have gone through the pipeline at it -- the first generation
+    starts on an empty chip, the second still inherits its convoys -- or the cap.  Returns the steps run."""
     n, t0 = 0, time.perf_counter()
     while n < max_frames and time.perf_counter() - t0 < max_seconds:
-        if all_settled(st.get_schedule()["settled"]):
+        sch = st.get_schedule()
+        if all_settled(sch["settled"] and done + n >= 3 * sch["frames_in_flight"]):
             break
         step()
         n += 1
@@ -236,8 +239,8 @@ def other_config_rates(M, schedules, budget_s):
     legs = [   # name, scene, width, height, spp, depth, shard, warm-up frames (pinned schedule), timed steps, schedule key
         ("c1", "default", 400, 225, 16, 8, None, 600, 3000, "c1_n1"),
         ("c2", "cover", 1200, 675, 64, 50, None, 30, 150, "c2_n1"),
-        ("c4", "cover-glass", 3840, 2160, 1024, 50, None, 2, 3, "c4_n1"),
-        ("c5", "stress", 1920, 1080, 4096, 50, None, 5, 4, "c5_n1"),
+        ("c4", "cover-glass", 3840, 2160, 1024, 50, None, 4, 8, "c4_n1"),
+        ("c5", "stress", 1920, 1080, 4096, 50, None, 4, 8, "c5_n1"),
         # (sixteen frames in flight: the pipeline's start -- sixteen launches at once -- takes two rounds of frames to even out)
         ("c5_share_1_of_8", "stress", 1920, 1080, 4096, 50, (0, 8), 32, 32, "c5_n8"),
     ]
@@ -282,8 +285,9 @@ def other_config_rates(M, schedules, budget_s):
         except Exception as e:           # noqa: BLE001 -- a failed side leg must not take the headline line with it
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
     out["seconds"] = time.perf_counter() - t_begin
-    out["note"] = ("side legs after the headline's timed region, one fresh context each, one mrt_redraw per step, stream RNG; "
-                   "`value` above stays the headline's")
+    out["note"] = ("side legs after the headline's timed region, one fresh context each, one mrt_redraw per step, stream RNG; SHORT "
+                   "runs from an empty pipeline to an empty pipeline (a few generations of frames: the fill and the drain cost the "
+                   "long-frame configs several per cent; the full runs are profiles/r05_bench_c*.json); `value` above stays the headline's")
     return out
 
 
@@ -467,7 +471,7 @@ def main():
         return bool(flag.item() > 0.5)
     settle_frames = 0
     if a.frames_per_step == 1 and a.steps > 0:
-        settle_frames = settle(st, step, fence, all_settled, 600, 30.0)
+        settle_frames = settle(st, step, fence, all_settled, 600, 30.0, done=a.warmup)
         if use_dist:
             box = [st.get_schedule()]
             dist.broadcast_object_list(box, src=0)
@@ -692,7 +696,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spheres, cam, width, height, a.depth, seed)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not use_dist and headline and a.config == "c3" and not a.no_other_configs and a.steps > 0:
-            out["other_configs"] = other_config_rates(M, schedules if a.schedule == "hint" else {}, 75.0)
+            out["other_configs"] = other_config_rates(M, schedules if a.schedule == "hint" else {}, 90.0)
 
     # ---- N > 1: the C ABI's own gathers on the same workload, after everything that is timed for `value`.  Non-fatal by
     # construction: any exception becomes {"error": ...}.  A HANG (a collective or a peer copy that never completes -- these
