@@ -473,14 +473,17 @@ def main():
     if a.frames_per_step == 1 and a.steps > 0:
         settle_frames = settle(st, step, fence, all_settled, 600, 30.0, done=a.warmup)
         if use_dist:
-            box = [st.get_schedule()]
-            dist.broadcast_object_list(box, src=0)
-            mine = st.get_schedule()
-            if box[0]["div"] and ((box[0]["div"], box[0]["mult"]) != (mine["div"], mine["mult"]) or not mine["settled"]):
-                st.set_schedule_hint(box[0]["div"], box[0]["mult"])
-                for _ in range(box[0]["frames_in_flight"]):
-                    step()
-                settle_frames += box[0]["frames_in_flight"]
+            before = st.get_schedule()
+            shared = mdist.share_schedule(st, 0)
+            if shared is not None and shared != (before["div"], before["mult"]):       # a new setting on this rank: fill its pipeline
+                n_fill = st.get_schedule()["frames_in_flight"]
+            else:
+                n_fill = 0
+            fill = torch.tensor([float(n_fill)], dtype=torch.float64, device=gather_device)
+            dist.all_reduce(fill, op=dist.ReduceOp.MAX)            # (every rank steps together: a step holds a collective)
+            for _ in range(int(fill.item())):
+                step()
+            settle_frames += int(fill.item())
             fence()
     schedule_before = st.get_schedule()
     c0 = st.read_counters()

@@ -22,7 +22,8 @@ static void usage() {
         "usage: native_runner [--width N] [--height N] [--samples-per-frame N] [--ray-depth N]\n"
         "                     [--max-framebuffer-weight F] [--frames N] [--warmup N] [--seed N] [--rng stream|counter]\n"
         "                     [--scene default|cover|cover-glass|stress | --scene-file FILE] [--save-scene FILE]\n"
-        "                     [--out FILE.pfm|FILE.ppm|FILE.png] [--device N | --gpus N | --devices a,b,...]\n");
+        "                     [--out FILE.pfm|FILE.ppm|FILE.png] [--device N | --gpus N | --devices a,b,...]\n"
+                         "                     [--schedule div,mult]\n");
 }
 
 int main(int argc, char** argv) {
@@ -33,6 +34,7 @@ int main(int argc, char** argv) {
     mrt_args args;
     mrt_args_default(&args);
     uint32_t frames = 1, warmup = 0, rng_mode = MRT_RNG_PIXEL_STREAM; uint64_t seed = 1; int device = 0;
+    uint32_t hint_div = 0, hint_mult = 0;
     std::string scene = "default", scene_file, save_scene, out;
     std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
@@ -57,6 +59,9 @@ int main(int argc, char** argv) {
         else if (a == "--scene") scene = v;
         else if (a == "--scene-file") scene_file = v;
         else if (a == "--save-scene") save_scene = v;
+        else if (a == "--schedule") {       // "div,mult": pin the launch schedule on every GPU (mrt_set_schedule_hint)
+            if (std::sscanf(v.c_str(), "%u,%u", &hint_div, &hint_mult) != 2) { std::fprintf(stderr, "--schedule wants div,mult\n"); return 2; }
+        }
         else if (a == "--out") out = v;
         else if (a == "--device") device = std::atoi(v.c_str());
         else if (a == "--gpus") { devices.clear(); for (int d = 0; d < std::atoi(v.c_str()); d++) devices.push_back(d); }
@@ -106,12 +111,19 @@ int main(int argc, char** argv) {
         TRY(ctxs[i], mrt_set_world(ctxs[i], spheres.data(), (size_t)n));
         TRY(ctxs[i], mrt_set_camera(ctxs[i], &cam));
         if (rng_mode != MRT_RNG_PIXEL_STREAM) TRY(ctxs[i], mrt_set_rng_mode(ctxs[i], rng_mode));
+        if (hint_div) TRY(ctxs[i], mrt_set_schedule_hint(ctxs[i], hint_div, hint_mult));
     }
     if (warmup) {           // untimed: the tile-cost estimate, buffers and peer mappings exist afterwards
         for (mrt_ctx* c : ctxs) TRY(c, mrt_render(c, warmup));
         if (n_gpus > 1) TRY(ctxs[0], mrt_gather(ctxs.data(), n_gpus, 0));
         for (mrt_ctx* c : ctxs) TRY(c, mrt_sync(c));
         for (mrt_ctx* c : ctxs) TRY(c, mrt_reset(c));
+        // every GPU renders an equal share of the same frame: one launch schedule for all of them -- the first context's, if its
+        // controller has settled (the setting is measured on the host's clock: GPUs may otherwise decide differently)
+        uint32_t sch[6] = {0, 0, 0, 0, 0, 0};
+        TRY(ctxs[0], mrt_get_schedule(ctxs[0], sch));
+        if (n_gpus > 1 && !hint_div && sch[0] != 0 && sch[2] != 0)
+            for (mrt_ctx* c : ctxs) TRY(c, mrt_set_schedule_hint(c, sch[0], sch[1]));
     }
     for (mrt_ctx* c : ctxs) TRY(c, mrt_sync(c));
     auto t0 = std::chrono::steady_clock::now();

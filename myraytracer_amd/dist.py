@@ -60,6 +60,21 @@ def gather_framebuffer(local: torch.Tensor, height: int, dst: int = 0,
     return None
 
 
+def share_schedule(state, src: int = 0, group=None):
+    """One launch schedule for every rank: broadcast rank `src`'s setting (mrt_get_schedule) and pin it everywhere
+    (mrt_set_schedule_hint).  The library measures its setting on each host's clock, so the ranks of a run -- equal shares of one
+    frame -- may otherwise settle differently.  Collective; returns the (div, mult) now in force, or None if `src` has none yet."""
+    mine = state.get_schedule()
+    box = [(mine["div"], mine["mult"]) if mine["div"] else None]
+    if dist.is_initialized():
+        dist.broadcast_object_list(box, src=src, group=group)
+    if box[0] is None:
+        return None
+    if box[0] != (mine["div"], mine["mult"]) or not mine["settled"]:
+        state.set_schedule_hint(*box[0])
+    return box[0]
+
+
 class _DevicePtr:
     """Wraps a raw device pointer owned by an mrt_ctx as a __cuda_array_interface__ object."""
 

@@ -66,6 +66,49 @@ def test_gather_unshard_world(tmp_path, oracle, mrt, world, height):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+class _FakeState:
+    """What share_schedule needs of a State (get_schedule / set_schedule_hint), without a GPU."""
+
+    def __init__(self, div, mult, settled):
+        self.sch = {"div": div, "mult": mult, "settled": settled}
+        self.pinned = None
+
+    def get_schedule(self):
+        return dict(self.sch)
+
+    def set_schedule_hint(self, div, mult):
+        self.pinned = (div, mult)
+        self.sch = {"div": div, "mult": mult, "settled": True}
+
+
+def _schedule_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from myraytracer_amd import dist as mdist
+    # rank 0 settled at a quarter width, eight in flight; rank 1's controller went elsewhere; rank 2 has not settled
+    st = [_FakeState(4, 2, True), _FakeState(8, 2, True), _FakeState(4, 2, False)][rank]
+    got = mdist.share_schedule(st, 0)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([got[0], got[1], -1 if st.pinned is None else st.pinned[0]]))
+    # a root that has no setting yet: nobody is pinned
+    st2 = [_FakeState(0, 1, False), _FakeState(8, 2, True), _FakeState(2, 2, True)][rank]
+    assert mdist.share_schedule(st2, 0) is None and st2.pinned is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_share_schedule_gives_every_rank_the_roots_setting(tmp_path, mrt):
+    """N > 1: the ranks render equal shares of one frame, and each library instance measures its schedule on its own host
+    clock; bench.py (and any caller) broadcasts rank 0's and pins it (mrt_set_schedule_hint) -- world 3 over gloo."""
+    world = 3
+    mp.spawn(_schedule_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(str(tmp_path / f"r{k}.npy")) for k in range(world)]
+    assert [tuple(x[:2]) for x in r] == [(4, 2)] * 3
+    assert r[0][2] == -1            # the root keeps what it has
+    assert r[1][2] == 4             # a rank that had settled elsewhere is pinned to the root's
+    assert r[2][2] == 4             # so is a rank that had not settled yet
+
+
 def test_band_layout_math(mrt):
     from myraytracer_amd import dist as mdist
     assert mdist.band_layout(1080, 1) == (135, 135)
