@@ -343,9 +343,10 @@ void build_clusters(const float* centers4, const float* radii, uint32_t n, float
 struct Hierarchy {
     std::vector<mrt::SphereRec> top, nodes;
     std::vector<uint32_t> member_index;
-    std::vector<mrt::BoxRec> boxes;           // levels 1 .. levels (the top last), level k at box_base[k]
+    std::vector<mrt::BoxFull> boxes;          // levels 1 .. levels (the top last), level k at box_base[k]
     uint32_t box_base[mrt::kMaxLevels + 1] = {0, 0, 0, 0, 0};
     bool box_quad = false;
+    float box_kc = 0.0f;                      // the slack's coefficient of X: one per scene
     uint32_t levels = 1, n_members = 0;       // n_members: level 0 including the direct spheres
     uint32_t level_base[mrt::kMaxLevels] = {0, 0, 0, 0};
     uint32_t n_direct = 0, direct_first = 0;
@@ -364,8 +365,11 @@ struct Hierarchy {
 // (each with >= 9 % to spare over 1.4143 x the bound; the 4.4e-14 / kc makes the quadratic form cover the test's own
 // rounding, 4 eps |p|_1, by the inequality of the means).  The quadratic form is far smaller at moderate distances, the
 // linear one at large distances from tiny spheres; the scene takes the one that is smaller at its own reach.
+// kc is ONE value per scene (round 5; r_min = the scene's smallest radius, which only makes K larger for the other boxes): the
+// kernel takes it from its arguments, and kpad -- the only other per-box part of K -- is folded into the extents the kernel
+// reads (pack_boxes), so a box is 24 bytes on the device.
 void build_boxes(const float* centers4, const float* radii, const std::vector<mrt::SphereRec>& members, Hierarchy& H) {
-    const mrt::BoxRec never_box{0.0f, 0.0f, 0.0f, -3.0e38f, -3.0e38f, -3.0e38f, 0.0f, 0.0f};
+    const mrt::BoxFull never_box{0.0f, 0.0f, 0.0f, -3.0e38f, -3.0e38f, -3.0e38f, 0.0f, 0.0f};
     H.boxes.clear();
     // the scene's reach and median radius decide the form of the slack
     double lo_all[3] = {1e300, 1e300, 1e300}, hi_all[3] = {-1e300, -1e300, -1e300};
@@ -379,14 +383,15 @@ void build_boxes(const float* centers4, const float* radii, const std::vector<mr
             hi_all[k] = std::max(hi_all[k], (double)centers4[4 * i + k]);
         }
     }
-    double reach = 0.0, r_med = 0.0;
+    double reach = 0.0, r_small = 1e300;
     if (!rr.empty()) {
         for (int k = 0; k < 3; k++) reach += (hi_all[k] - lo_all[k]) * (hi_all[k] - lo_all[k]);
         reach = std::sqrt(reach);
-        std::nth_element(rr.begin(), rr.begin() + rr.size() / 2, rr.end());
-        r_med = rr[rr.size() / 2];
+        r_small = *std::min_element(rr.begin(), rr.end());
     }
-    H.box_quad = 1.3e-6 / std::max(r_med, 1e-300) * reach < 1.5e-3 * 2.0;      // quadratic slack at the reach < 2 x the linear one
+    // (by the scene's SMALLEST radius, since kc is one value per scene: a scene with a few tiny spheres takes the linear form)
+    H.box_quad = 1.3e-6 / std::max(r_small, 1e-300) * reach < 1.5e-3 * 2.0;      // quadratic slack at the reach < 2 x the linear one
+    const double kc_scene = H.box_quad ? 1.3e-6 / std::max(r_small, 1e-30) : 1.5e-3;
     auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; };
     for (uint32_t k = 1; k <= H.levels; k++) {
         H.box_base[k] = (uint32_t)H.boxes.size();
@@ -394,13 +399,12 @@ void build_boxes(const float* centers4, const float* radii, const std::vector<mr
         const size_t span = (size_t)1 << (2 * k);
         for (size_t j = 0; j < n_k; j++) {
             const size_t m0 = j * span, m1 = std::min(members.size(), (j + 1) * span);
-            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, r_min = 1e300;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
             bool any = false;
             for (size_t m = m0; m < m1; m++) {
                 if (!std::isfinite(members[m].neg_r2)) continue;
                 const uint32_t i = H.member_index[m];
                 const double r = std::fabs((double)radii[i]);
-                r_min = std::min(r_min, r);
                 for (int q = 0; q < 3; q++) {
                     lo[q] = std::min(lo[q], (double)centers4[4 * i + q] - r);
                     hi[q] = std::max(hi[q], (double)centers4[4 * i + q] + r);
@@ -408,7 +412,7 @@ void build_boxes(const float* centers4, const float* radii, const std::vector<mr
                 any = true;
             }
             if (!any) { H.boxes.push_back(never_box); continue; }
-            mrt::BoxRec b;
+            mrt::BoxFull b;
             float c[3], e[3];
             double e1 = 0.0, e2 = 0.0;
             for (int q = 0; q < 3; q++) {
@@ -419,16 +423,28 @@ void build_boxes(const float* centers4, const float* radii, const std::vector<mr
                 e2 += (double)e[q] * (double)e[q];
             }
             b.cx = c[0]; b.cy = c[1]; b.cz = c[2]; b.ex = e[0]; b.ey = e[1]; b.ez = e[2];
-            if (H.box_quad) {
-                const double kc = 1.3e-6 / std::max(r_min, 1e-30);
-                b.kc = up(kc);
-                b.kpad = up((double)b.kc * e2 + 4.4e-14 / kc);
-            } else {
-                b.kc = 1.5e-3f;
-                b.kpad = up(1.5e-3 * e1);
-            }
+            b.kc = H.box_quad ? up(kc_scene) : 1.5e-3f;
+            b.kpad = H.box_quad ? up((double)b.kc * e2 + 4.4e-14 / kc_scene) : up(1.5e-3 * e1);
             H.boxes.push_back(b);
         }
+    }
+    H.box_kc = H.box_quad ? up(kc_scene) : 1.5e-3f;
+}
+
+// What the kernel reads of a box (mrt_internal.h, BoxRec): the centre and the extents with kpad folded in, e' = e + kpad rounded
+// up.  The test on the axis d x e_i then has the slack kc X + kpad (|d_j| + |d_k|) instead of kc X + kpad; what is needed there is
+// rho |d x e_i| + (the test's rounding) (|d_j| + |d_k|), rho the distance beyond the box the line of a candidate can pass, and
+// |d x e_i| <= s = |d_j| + |d_k| <= 1.4143: both sides are linear in s on [0, 1] and on [1, 1.4143], at s = 0 the left side is
+// kc X >= 0, and at s = 1 and s = 1.4143 the inequality is the one build_boxes provides (kc X + kpad >= 1.4143 rho + the
+// rounding: tests/test_hierarchy_host.py checks it box by box).
+void pack_boxes(const std::vector<mrt::BoxFull>& full, std::vector<mrt::BoxRec>& out) {
+    auto up = [](double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; };
+    out.resize(full.size());
+    for (size_t i = 0; i < full.size(); i++) {
+        const mrt::BoxFull& b = full[i];
+        const bool real = b.ex >= 0.0f && b.ex < 1.0e37f;           // (never-hit: -3e38; opened wide: 3e37)
+        out[i] = mrt::BoxRec{b.cx, b.cy, b.cz, real ? up((double)b.ex + (double)b.kpad) : b.ex, real ? up((double)b.ey + (double)b.kpad) : b.ey,
+                             real ? up((double)b.ez + (double)b.kpad) : b.ez};
     }
 }
 
@@ -436,8 +452,8 @@ void build_boxes(const float* centers4, const float* radii, const std::vector<mr
 // `levels`, levels - 1 = the clusters = level 1) at o_t = n_top (4^t - 1) / 3, n_top = the padded top: the children of node g
 // are 4 g + n_top .. + 3 whatever its depth, so a work item needs no level.  Slots without a node hold never-hit boxes.
 // `open`: every real box opened wide (extents 3e37: the test never rejects) -- the A/B form of mrt_debug_set_boxes(0).
-void boxes_top_down(const Hierarchy& H, bool open, std::vector<mrt::BoxRec>& out, uint32_t* cluster_first, uint32_t* cluster_parent_first) {
-    const mrt::BoxRec never_box{0.0f, 0.0f, 0.0f, -3.0e38f, -3.0e38f, -3.0e38f, 0.0f, 0.0f};
+void boxes_top_down(const Hierarchy& H, bool open, std::vector<mrt::BoxFull>& out, uint32_t* cluster_first, uint32_t* cluster_parent_first) {
+    const mrt::BoxFull never_box{0.0f, 0.0f, 0.0f, -3.0e38f, -3.0e38f, -3.0e38f, 0.0f, 0.0f};
     const size_t n_top = H.top.size();
     size_t o[mrt::kMaxLevels + 1];
     o[0] = 0;
@@ -447,7 +463,7 @@ void boxes_top_down(const Hierarchy& H, bool open, std::vector<mrt::BoxRec>& out
         const uint32_t k = H.levels - t;                 // the level at this depth
         const size_t first = H.box_base[k], last = k < H.levels ? H.box_base[k + 1] : H.boxes.size();
         for (size_t j = 0; j < last - first && j < (n_top << (2 * t)); j++) {
-            mrt::BoxRec b = H.boxes[first + j];
+            mrt::BoxFull b = H.boxes[first + j];
             if (open && b.ex >= 0.0f) b.ex = b.ey = b.ez = 3.0e37f;
             out[o[t] + j] = b;
         }
@@ -987,13 +1003,17 @@ int mrt_set_world_raw(mrt_ctx* c, const void* world, size_t world_bytes, const f
     HIP_TRY(c, upload((void**)&c->d_clusters, hier.top.data(), hier.top.size() * sizeof(mrt::SphereRec)));
     HIP_TRY(c, upload((void**)&c->d_nodes, hier.nodes.data(), hier.nodes.size() * sizeof(mrt::SphereRec)));
     if (hier.n_members > 1024u) {           // large scenes (the kernel's !SMALL layouts) walk the boxes
+        std::vector<mrt::BoxFull> full;
         std::vector<mrt::BoxRec> dev;
-        boxes_top_down(hier, false, dev, &c->box_cluster_first, &c->box_cluster_parent_first);
+        boxes_top_down(hier, false, full, &c->box_cluster_first, &c->box_cluster_parent_first);
+        pack_boxes(full, dev);
         HIP_TRY(c, upload((void**)&c->d_boxes, dev.data(), dev.size() * sizeof(mrt::BoxRec)));
-        boxes_top_down(hier, true, dev, &c->box_cluster_first, &c->box_cluster_parent_first);
+        boxes_top_down(hier, true, full, &c->box_cluster_first, &c->box_cluster_parent_first);
+        pack_boxes(full, dev);
         HIP_TRY(c, upload((void**)&c->d_boxes_open, dev.data(), dev.size() * sizeof(mrt::BoxRec)));
     }
     c->box_quad = hier.box_quad;
+    c->box_kc = hier.box_kc;
     {
         std::vector<uint16_t> top_mfma;
         double max_c2 = 0.0, med_r2 = 0.0;
@@ -1191,6 +1211,7 @@ static void fill_scene_params(const mrt_ctx* c, mrt::KParams& p) {
     p.boxes = c->boxes_mode == 0 ? c->d_boxes_open : c->d_boxes;
     p.box_cluster_first = c->box_cluster_first; p.box_cluster_parent_first = c->box_cluster_parent_first;
     p.box_quad = c->box_quad ? 1u : 0u;
+    p.box_kc = c->box_kc;
     p.n_direct = c->n_direct; p.direct_first = c->direct_first;
     for (uint32_t k = 0; k < mrt::kMaxDirect; k++) { p.direct[k] = c->direct[k]; p.direct_index[k] = c->direct_index[k]; }
     p.cus = c->cus;
@@ -1699,12 +1720,18 @@ int mrt_debug_build_boxes_top_down(const mrt_sphere* spheres, size_t n, uint32_t
     }
     Hierarchy h;
     build_hierarchy(centers.data(), radii.data(), (uint32_t)n, 8.0f, max_levels, top_target, h);
-    std::vector<mrt::BoxRec> dev;
+    std::vector<mrt::BoxFull> full;
+    std::vector<mrt::BoxRec> packed;
     uint32_t cf = 0, cpf = 0;
-    boxes_top_down(h, open != 0, dev, &cf, &cpf);
+    boxes_top_down(h, open != 0, full, &cf, &cpf);
+    pack_boxes(full, packed);
+    // what the kernel reads, in the 8-float form of mrt_debug_build_boxes: centre, the extents WITH kpad folded in, the scene's kc, 0
+    std::vector<mrt::BoxFull> dev(full.size());
+    for (size_t i = 0; i < full.size(); i++)
+        dev[i] = mrt::BoxFull{packed[i].cx, packed[i].cy, packed[i].cz, packed[i].ex, packed[i].ey, packed[i].ez, full[i].ex >= 0.0f ? h.box_kc : 0.0f, 0.0f};
     info[0] = h.levels; info[1] = (uint32_t)dev.size(); info[2] = (uint32_t)h.top.size(); info[3] = cf; info[4] = cpf;
     if (boxes_out && boxes_cap < dev.size()) return MRT_ERR_TOO_SMALL;
-    if (boxes_out) std::memcpy(boxes_out, dev.data(), dev.size() * sizeof(mrt::BoxRec));
+    if (boxes_out) std::memcpy(boxes_out, dev.data(), dev.size() * sizeof(mrt::BoxFull));
     return MRT_OK;
 }
 
@@ -1723,7 +1750,7 @@ int mrt_debug_build_boxes(const mrt_sphere* spheres, size_t n, uint32_t max_leve
     info[0] = h.levels; info[1] = (uint32_t)h.boxes.size(); info[2] = h.box_quad ? 1u : 0u;
     for (uint32_t k = 0; k <= mrt::kMaxLevels; k++) info[3 + k] = h.box_base[k];
     if (boxes_out && boxes_cap < h.boxes.size()) return MRT_ERR_TOO_SMALL;
-    if (boxes_out) std::memcpy(boxes_out, h.boxes.data(), h.boxes.size() * sizeof(mrt::BoxRec));
+    if (boxes_out) std::memcpy(boxes_out, h.boxes.data(), h.boxes.size() * sizeof(mrt::BoxFull));
     return MRT_OK;
 }
 

@@ -171,17 +171,20 @@ __device__ __forceinline__ void test8(const Sph8& g, V3 o, V3 ds, uint32_t& bits
 // K = kc X + kpad, X = |p|^2 or |p|_1 (per scene), is the slack that makes it CONSERVATIVE against the reference's own
 // rounding: a member whose computed discriminant is >= 0 has the line within sqrt(r^2 + 14 eps |oc|^2 / a) of its centre,
 // i.e. up to min(14 eps |oc|^2 / (2 r), sqrt(14 eps) |oc|) beyond its surface, hence beyond its box; the host (api.cpp,
-// build_boxes) sets kc and kpad per box so that K covers 1.4143 x that for every member under the node, plus the
-// test's own rounding (4 eps |p|_1; the right-hand side's three roundings are in the extents).  A never-hit box has extents
+// build_boxes) sets kc per scene and kpad per box so that K covers 1.4143 x that for every member under the node, plus the
+// test's own rounding (4 eps |p|_1; the right-hand side's three roundings are in the extents).  The kernel reads kpad FOLDED
+// INTO THE EXTENTS (e + kpad: on the axis d x e_i that is a slack of kpad (|d_j| + |d_k|), which covers what "+ kpad" covered:
+// api.cpp, pack_boxes) and kc from its arguments, so a box is 24 bytes.  A never-hit box has extents
 // -3e38: some axis' right-hand side is then hugely negative (a unit direction has a component >= 0.57).
 // 24 VALU: 3 + 3 (X) + 1 (K) + 3 x 5 + 2.
+// (c, e): a BoxRec -- the centre and the half extents with kpad folded in (mrt_internal.h); kc: the scene's coefficient of X.
 template <bool QUAD>
-__device__ __forceinline__ uint32_t box_separated_bits(const float4 b0, const float4 b1, V3 o, V3 d) {
-    const float px = o.x - b0.x, py = o.y - b0.y, pz = o.z - b0.z;
+__device__ __forceinline__ uint32_t box_separated_bits(const V3 c, const V3 e, const float kc, V3 o, V3 d) {
+    const float px = o.x - c.x, py = o.y - c.y, pz = o.z - c.z;
     const float X = QUAD ? __builtin_fmaf(pz, pz, __builtin_fmaf(py, py, px * px))
                          : (__builtin_fabsf(px) + __builtin_fabsf(py)) + __builtin_fabsf(pz);
-    const float K = __builtin_fmaf(b1.z, X, b1.w);
-    const float ex = b0.w, ey = b1.x, ez = b1.y;
+    const float K = kc * X;
+    const float ex = e.x, ey = e.y, ez = e.z;
     const float adx = __builtin_fabsf(d.x), ady = __builtin_fabsf(d.y), adz = __builtin_fabsf(d.z);
     const float sx = __builtin_fmaf(ey, adz, __builtin_fmaf(ez, ady, K)) - __builtin_fabsf(__builtin_fmaf(-pz, d.y, py * d.z));
     const float sy = __builtin_fmaf(ez, adx, __builtin_fmaf(ex, adz, K)) - __builtin_fabsf(__builtin_fmaf(-px, d.z, pz * d.x));
@@ -190,8 +193,8 @@ __device__ __forceinline__ uint32_t box_separated_bits(const float4 b0, const fl
     return __float_as_uint(sx) | __float_as_uint(sy) | __float_as_uint(sz);
 }
 template <bool QUAD>
-__device__ __forceinline__ bool box_may_touch(const float4 b0, const float4 b1, V3 o, V3 d) {
-    return (int32_t)box_separated_bits<QUAD>(b0, b1, o, d) >= 0;
+__device__ __forceinline__ bool box_may_touch(const V3 c, const V3 e, const float kc, V3 o, V3 d) {
+    return (int32_t)box_separated_bits<QUAD>(c, e, kc, o, d) >= 0;
 }
 
 // ---- the same conservative test on the matrix cores -------------------------------------------------
@@ -440,7 +443,8 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
     } else {
         float4* const dst = reinterpret_cast<float4*>(lds_raw);
         const float4* const src = reinterpret_cast<const float4*>(P.boxes);
-        for (uint32_t i = threadIdx.x; i < 2u * P.box_lds_count; i += 64u * kWavesPerGroup) dst[i] = src[i];
+        // (24-byte records, an even count: whole float4s)
+        for (uint32_t i = threadIdx.x; i < (P.box_lds_count * (uint32_t)sizeof(BoxRec)) / 16u; i += 64u * kWavesPerGroup) dst[i] = src[i];
         __syncthreads();
     }
 
@@ -852,11 +856,17 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                     // its first box_lds boxes, in LDS (address-space qualified: as two generic pointers hipcc merged the owners' two
                     // sources into ONE flat load of a selected pointer, which goes down the texture path whatever it reads)
                     typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
                     typedef const f32x4 __attribute__((address_space(3)))* LdsBoxPtr;
                     typedef const f32x4 __attribute__((address_space(1)))* GlobalBoxPtr;
+                    typedef const f32x2 __attribute__((address_space(3)))* LdsBox2Ptr;          // one box = 3 x 8 bytes, 8-byte aligned
+                    typedef const f32x2 __attribute__((address_space(1)))* GlobalBox2Ptr;
                     auto f4 = [](const f32x4 v) { return make_float4(v.x, v.y, v.z, v.w); };
                     const LdsBoxPtr bxs_lds = (LdsBoxPtr)lds_raw;
                     const GlobalBoxPtr bxs_g = (GlobalBoxPtr)P.boxes;
+                    const LdsBox2Ptr bx2_lds = (LdsBox2Ptr)lds_raw;
+                    const GlobalBox2Ptr bx2_g = (GlobalBox2Ptr)P.boxes;
+                    const float box_kc = P.box_kc;
                     const uint32_t box_lds = P.box_lds_count;
                     const bool top_in_lds = box_lds >= n_padded;
                     const uint32_t cluster_parent_first = P.box_cluster_parent_first;
@@ -886,15 +896,18 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                     }
                                     return code;
                                 };
-                                auto fetch_box = [&](const uint32_t code, float4& b0, float4& b1) {
+                                auto fetch_box = [&](const uint32_t code, V3& bc, V3& be) {
                                     const uint32_t g = code & 0x7FFFFFFFu;
-                                    if (top_in_lds) { b0 = f4(bxs_lds[2u * g]); b1 = f4(bxs_lds[2u * g + 1u]); }
-                                    else { b0 = f4(bxs_g[2u * (size_t)g]); b1 = f4(bxs_g[2u * (size_t)g + 1u]); }
+                                    f32x2 w0, w1, w2;
+                                    if (top_in_lds) { w0 = bx2_lds[3u * g]; w1 = bx2_lds[3u * g + 1u]; w2 = bx2_lds[3u * g + 2u]; }
+                                    else { w0 = bx2_g[3u * (size_t)g]; w1 = bx2_g[3u * (size_t)g + 1u]; w2 = bx2_g[3u * (size_t)g + 2u]; }
+                                    bc = v3(w0.x, w0.y, w1.x);
+                                    be = v3(w1.y, w2.x, w2.y);
                                 };
                                 // a candidate whose box the ray's line may touch goes on the queue (one comparison decides both: the
                                 // separation's sign bit, or the missing candidate bit)
-                                auto test_push = [&](const uint32_t code, const float4 b0, const float4 b1) {
-                                    const bool keep = (int32_t)(box_separated_bits<QUAD>(b0, b1, o, d) | ~code) >= 0;
+                                auto test_push = [&](const uint32_t code, const V3 bc, const V3 be) {
+                                    const bool keep = (int32_t)(box_separated_bits<QUAD>(bc, be, box_kc, o, d) | ~code) >= 0;
                                     const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
                                     if (keep) dst[qn + rank_in(km)] = owner_bits | (code & 0x7FFFFFFFu);
                                     qn += (uint32_t)__popcll(km);
@@ -904,7 +917,7 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                                 // the loop, on alternating register sets: carried over a single-trip loop the box fetched ahead had to be
                                 // COPIED at the end of every trip, which also waited for it there
                                 uint32_t ca = next_candidate(), cb, left;
-                                float4 a0, a1, b0, b1;
+                                V3 a0, a1, b0, b1;
                                 fetch_box(ca, a0, a1);
                                 for (;;) {
                                     cb = next_candidate();
@@ -949,22 +962,25 @@ __global__ void __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_wav
                         } else {
                             const uint32_t c0 = 4u * g + n_padded;                    // the first child, in the same numbering
                             // (from LDS when the children of every item of the round are among the boxes held there)
-                            float4 b[8];
+                            // (the four children: 4 x 24 = 96 contiguous bytes, 16-byte aligned -- c0 is a multiple of 4)
+                            float4 b[6];
                             if (__builtin_amdgcn_ballot_w64(act && c0 + 4u > box_lds) == 0ull) {
-                                const LdsBoxPtr bx = bxs_lds + 2u * c0;
+                                const LdsBoxPtr bx = bxs_lds + 6u * (c0 >> 2);
 #pragma unroll
-                                for (int q = 0; q < 8; q++) b[q] = f4(bx[q]);
+                                for (int q = 0; q < 6; q++) b[q] = f4(bx[q]);
                             } else {
-                                const GlobalBoxPtr bx = bxs_g + 2u * (size_t)c0;
+                                const GlobalBoxPtr bx = bxs_g + 6u * (size_t)(c0 >> 2);
 #pragma unroll
-                                for (int q = 0; q < 8; q++) b[q] = f4(bx[q]);
+                                for (int q = 0; q < 6; q++) b[q] = f4(bx[q]);
                             }
+                            const V3 bc[4] = {v3(b[0].x, b[0].y, b[0].z), v3(b[1].z, b[1].w, b[2].x), v3(b[3].x, b[3].y, b[3].z), v3(b[4].z, b[4].w, b[5].x)};
+                            const V3 be[4] = {v3(b[0].w, b[1].x, b[1].y), v3(b[2].y, b[2].z, b[2].w), v3(b[3].w, b[4].x, b[4].y), v3(b[5].y, b[5].z, b[5].w)};
                             bool h[4];
                             unsigned long long hm[4];
                             const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(act);
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
-                                h[q] = box_may_touch<QUAD>(b[2 * q], b[2 * q + 1], ro, rd);
+                                h[q] = box_may_touch<QUAD>(bc[q], be[q], box_kc, ro, rd);
                                 hm[q] = __builtin_amdgcn_ballot_w64(h[q]) & act_mask;
                             }
                             sn = start;

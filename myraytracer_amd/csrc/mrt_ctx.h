@@ -43,6 +43,7 @@ struct mrt_ctx {
     mrt::BoxRec* d_boxes_open = nullptr;
     uint32_t box_cluster_first = 0, box_cluster_parent_first = 0;
     bool box_quad = false;
+    float box_kc = 0.0f;
     int boxes_mode = 1;                    // mrt_debug_set_boxes: 0 = the boxes never reject (diagnostic), 1 / 2 = they do
     float cluster_factor = 8.0f;           // grow a cluster while its enclosing radius <= factor * largest member radius
     // hierarchy depth rule (build_hierarchy): levels are added while the top has more than top_target records; 0 = automatic

@@ -29,11 +29,16 @@ constexpr uint32_t kMaxDirect = 4;       // very large spheres tested by every r
 struct alignas(16) SphereRec { float cx, cy, cz, neg_r2; };
 
 // Axis-aligned box of the member spheres under a node of the hierarchy (large scenes: the walk's second, much tighter bound
-// -- a kd-built group of spheres on a plane fills its box, not its bounding sphere): centre, half extents (measured from the
-// f32 centre, rounded up) and the two coefficients of the test's slack K = kc X + kpad (kernels.hip, box_may_touch;
-// X = |p|^2 or |p|_1 of the ray origin relative to the centre, per scene: KParams::box_quad).  A never-hit box has
-// extents -3e38.
-struct alignas(16) BoxRec { float cx, cy, cz, ex, ey, ez, kc, kpad; };
+// -- a kd-built group of spheres on a plane fills its box, not its bounding sphere).
+// BoxFull: what the host derives per node (api.cpp, build_boxes) and the diagnostics report: centre, half extents (measured
+// from the f32 centre, rounded up) and the two coefficients of the test's slack K = kc X + kpad (X = |p|^2 or |p|_1 of the ray
+// origin relative to the centre, per scene: KParams::box_quad); kc is ONE value per scene (KParams::box_kc).
+// BoxRec: what the kernel reads, 24 bytes: the centre and the half extents WITH kpad folded in (e + kpad, rounded up) -- on the
+// axis d x e_i the slack kpad (|d_j| + |d_k|) that gives covers what the "+ kpad" of the test covered (api.cpp, pack_boxes) --
+// so an inner item's four children are 96 bytes instead of 128: a large scene's rounds wait for the vector-memory path's
+// 64 bytes per clock and CU.  A never-hit box has extents -3e38.
+struct BoxFull { float cx, cy, cz, ex, ey, ez, kc, kpad; };
+struct alignas(8) BoxRec { float cx, cy, cz, ex, ey, ez; };
 
 // Everything one raytrace pass needs, passed by value as kernel arguments (-> SGPRs).
 // Mirrors the three bind groups of State::redraw (lib.rs:262-265): Locals + seeds,
@@ -79,6 +84,7 @@ struct KParams {
     // the capacity of the wave's work stack.  Null / 0 for small scenes.
     const BoxRec* boxes;
     uint32_t box_cluster_first, box_cluster_parent_first, box_quad;
+    float box_kc;               // the slack's coefficient of X, one per scene (api.cpp, build_boxes)
     // the first box_lds_count boxes of that numbering (the swept top, and the level below it where it fits) are copied into
     // the workgroup's LDS: what the owners' filter and the first inner rounds read (kernels.hip)
     uint32_t box_lds_count;

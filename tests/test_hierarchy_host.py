@@ -275,7 +275,7 @@ def test_lds_footprint_keeps_the_residency_the_kernels_are_built_for(mrt):
     assert h["levels"] == 1 and groups == 5 and lds * 5 <= 160 * 1024, (lds, groups)
     h, lds, groups, cap = layout(mrt.scene_stress(1, 100)[0])
     assert h["levels"] == 4 and len(h["top"]) == 64
-    # every byte used: the boxes of the top and of the level below it (5 x 64 x 32 B, shared by the group's waves), the stacks
+    # every byte used: the boxes of the top and of the level below it (5 x 64 x 24 B, shared by the group's waves), the stacks
     assert groups == 4 and 4 * lds == 160 * 1024 and cap >= 480, (lds, groups, cap)
     # any large scene, whatever its hierarchy: 4 groups per CU and a work stack that holds a round's pushes several times over
     for n_side, levels, target in [(36, 4, 0), (36, 1, 64), (50, 2, 8), (70, 4, 16), (100, 3, 256)]:
@@ -288,7 +288,9 @@ def test_the_kernels_top_down_numbering_of_the_boxes(mrt):
     (kernels.hip) -- over the array api.cpp's boxes_top_down lays out.  Against the level-ordered boxes of
     mrt_debug_build_boxes: every node sits where the rule puts it (top record j at j; child q of the node at level k, index j,
     at 4 g + n_top + q), every other slot is a never-hit box, the cluster level and its parents start where the kernel is
-    told, and the opened-wide copy differs only in the extents of real boxes."""
+    told, and the opened-wide copy differs only in the extents of real boxes.  The array is what the kernel reads (24 bytes a box:
+    centre + extents, reported here as 8 floats): the extents carry the level-ordered box's kpad (e + kpad, rounded up: api.cpp
+    pack_boxes), kc is the scene's one value."""
     L = _lib.load()
     for name, sc in scenes(mrt):
         for max_levels, target in [(4, 0), (4, 16), (3, 8), (2, 64), (1, 64)]:
@@ -305,18 +307,31 @@ def test_the_kernels_top_down_numbering_of_the_boxes(mrt):
             assert n_dev == o[levels] and cluster_first == o[levels - 1] and cluster_parent_first == (o[levels - 2] if levels >= 2 else 0)
             placed = np.zeros(n_dev, bool)
             host, base = b["boxes"], b["base"]
+            real_host = host[:, 3] >= 0
+            kc_scene = np.float32(host[real_host][:, 6].max()) if real_host.any() else np.float32(0)
+            assert (host[real_host][:, 6] == kc_scene).all(), name              # ONE kc per scene
+
+            def device_form(h):
+                """a level-ordered box as the kernel reads it"""
+                if not h[3] >= 0:
+                    return np.array([h[0], h[1], h[2], h[3], h[4], h[5], 0, 0], np.float32)
+                e = h[3:6].astype(np.float64) + np.float64(h[7])
+                up = e.astype(np.float32)
+                up = np.where(up.astype(np.float64) < e, np.nextafter(up, np.float32(np.inf)), up)
+                return np.array([h[0], h[1], h[2], up[0], up[1], up[2], kc_scene, 0], np.float32)
             for t in range(levels):
                 k = levels - t                               # the level at depth t
                 first = base[k]
                 last = base[k + 1] if k < levels else len(host)
                 for j in range(last - first):
                     g = o[t] + j
-                    assert np.array_equal(dev[g].view(np.uint32), host[first + j].view(np.uint32)), (name, k, j)
+                    assert np.array_equal(dev[g].view(np.uint32), device_form(host[first + j]).view(np.uint32)), (name, k, j)
+                    assert (dev[g][3:6] >= host[first + j][3:6] + host[first + j][7]).all() or not host[first + j][3] >= 0
                     placed[g] = True
                     if t + 1 < levels and host[first + j][3] >= 0:          # a real node: its children by the kernel's rule
                         kids = base[k - 1] + 4 * j
                         for q in range(4):
-                            assert np.array_equal(dev[4 * g + n_top + q].view(np.uint32), host[kids + q].view(np.uint32)), (name, k, j, q)
+                            assert np.array_equal(dev[4 * g + n_top + q].view(np.uint32), device_form(host[kids + q]).view(np.uint32)), (name, k, j, q)
             assert (dev[~placed][:, 3:6] == np.float32(-3.0e38)).all(), name          # never-hit everywhere else
             real = dev[:, 3] >= 0
             assert np.array_equal(wide[~real].view(np.uint32), dev[~real].view(np.uint32))
