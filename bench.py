@@ -323,6 +323,8 @@ def main():
                     help="hint (default): pin the launch schedule profiles/schedules.json holds for this workload, if any "
                          "(mrt_set_schedule_hint); measure: let the library's controller find it -- either way the run warms up until "
                          "the schedule is final, and the line says which and what it was")
+    ap.add_argument("--hint", default="", help="div,mult: pin THIS launch schedule instead (e.g. 1,1 under rocprofv3 --pmc, which runs the "
+                                               "launches one at a time: a full-width launch then has the chip the counters are divided by)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N = 1 headline run: skip the side legs after the timed region that put C1, C2, C4, C5 and C5's 1/8 share into "
                          "the line (other_configs)")
@@ -409,6 +411,9 @@ def main():
     schedules = load_schedules()
     sched_key = f"{a.config}_n{world}"
     pinned = schedules.get(sched_key) if (a.schedule == "hint" and headline and a.frames_per_step == 1) else None
+    if a.hint:
+        pinned = dict(zip(("div", "mult"), (int(x) for x in a.hint.split(","))))
+        sched_key = "--hint " + a.hint
     if pinned:
         st.set_schedule_hint(int(pinned["div"]), int(pinned["mult"]))
     sweep_variant = st.debug_sweep_variant() or 1
@@ -627,7 +632,7 @@ def main():
             # max(2, div) x mult frames in flight)
             "schedule": {"div": schedule_after["div"], "mult": schedule_after["mult"], "final": schedule_after["settled"],
                          "frames_in_flight": schedule_after["frames_in_flight"],
-                         "source": (f"pinned: profiles/schedules.json[{sched_key}]" if pinned else
+                         "source": ((f"pinned: {sched_key}" if a.hint else f"pinned: profiles/schedules.json[{sched_key}]") if pinned else
                                     "measured by the library's controller during the untimed steps"),
                          "settle_frames": settle_frames,
                          "changed_during_timed_steps": (schedule_before["div"], schedule_before["mult"]) != (schedule_after["div"], schedule_after["mult"]),

@@ -1285,7 +1285,7 @@ static mrt::WidthWorkload width_workload(const mrt_ctx* c, bool counter) {
 // its convoys: judged on those, C3 read 4 % faster at a quarter width, where it renders 2 % less)
 static void width_restart_measurement(mrt_ctx* c) {
     c->width_timing = false;
-    c->width_valid_from = c->frame_seq + 2u * mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots);
+    c->width_valid_from = c->frame_seq + 2u * mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots);
     c->stat_base.valid = c->stat_last.valid = false;
 }
 
@@ -1398,7 +1398,14 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
         mrt::width_policy_step(c->width, w, m);
         if (c->width.settled) {
             if (trace) std::fprintf(stderr, "mrt width: settled at div %u x %u\n", c->width.div, c->width.mult);
-            c->width_memo.push_back({w.n_tiles, w.spp, w.n_members > 1024u ? 1u : 0u, w.counter, c->n_spheres, c->width.div, c->width.mult});
+            const mrt_ctx::WidthMemo memo{w.n_tiles, w.spp, w.n_members > 1024u ? 1u : 0u, w.counter, c->n_spheres, c->width.div, c->width.mult};
+            bool known = false;
+            for (auto& m : c->width_memo)
+                if (m.n_tiles == memo.n_tiles && m.spp == memo.spp && m.large == memo.large && m.counter == memo.counter && m.n_spheres == memo.n_spheres) {
+                    m = memo;
+                    known = true;
+                }
+            if (!known) c->width_memo.push_back(memo);
         }
         width_restart_measurement(c);
     }

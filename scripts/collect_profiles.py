@@ -11,7 +11,9 @@ names = {"bench_n1.json": "bench_n1.json", "bench_c4.json": "bench_c4_n1.json", 
          "bench_interactive_x32.json": "bench_interactive_x32_n1.json", "bench_forced_dist.json": "bench_forced_dist_n1.json",
          "rehearsal_gloo_n2.json": "rehearsal_gloo_n2_one_gpu.json", "config_rates.txt": "config_rates.txt",
          "shard_throughput.txt": "shard_throughput.txt", "c3_phase.txt": "c3_phase_profile.txt", "c5_phase.txt": "c5_phase_profile.txt",
-         "interactive_phase.txt": "interactive_phase_profile.txt"}
+         "interactive_phase.txt": "interactive_phase_profile.txt", "bench_c2_again.json": "bench_c2_again_n1.json",
+         "bench_c2_measure.json": "bench_c2_measure_n1.json", "bench_n1_measure.json": "bench_measure_n1.json",
+         "shard_occupancy.txt": "shard_occupancy.txt", "controller_outcomes.txt": "controller_outcomes.txt", "viewer_rates.txt": "viewer_rates.txt"}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p):

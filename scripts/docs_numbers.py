@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DOCS = ("DESIGN.md", "README.md")
-R = "r04"
+R = "r05"
 
 
 def _json(name):
@@ -61,9 +61,17 @@ TOKENS = {
     "INTERACTIVE_X32_VALUE": (lambda: _json(f"{R}_bench_interactive_x32_n1.json")["value"], ",.0f"),
     "SHARD8_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0")[0], ",.0f"),
     "SHARD8_UTIL": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0")[1], ".2f"),
-    # (the third 0/8 line of the file: the same share with round 3's schedule, MRT_SLOTS=2 -- see scripts/refresh_measurements.sh)
-    "SHARD8_OLD_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0", 1)[0], ",.0f"),
-    "SHARD8_OLD_UTIL": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0", 1)[1], ".2f"),
+    # (the second / third 0/8 line of the file: the same share with round 4's schedule, MRT_HINT=8,1, and with round 3's,
+    # MRT_SLOTS=2 -- see scripts/refresh_measurements.sh)
+    "SHARD8_R4_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0", 1)[0], ",.0f"),
+    "SHARD8_R4_UTIL": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0", 1)[1], ".2f"),
+    "SHARD8_OLD_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0", 2)[0], ",.0f"),
+    "SHARD8_OLD_UTIL": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/8 rng_mode 0", 2)[1], ".2f"),
+    "C5_WHOLE_REDRAW_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/1 rng_mode 0")[0], ",.0f"),
+    "C4SHARD_AUTO_VALUE": (lambda: _shard(r"^cover-glass 3840x2160x1024 shard 0/8 rng_mode 0", 1)[0], ",.0f"),
+    "C2_AGAIN_VALUE": (lambda: _json(f"{R}_bench_c2_again_n1.json")["value"], ",.0f"),
+    "C2_MEASURE_VALUE": (lambda: _json(f"{R}_bench_c2_measure_n1.json")["value"], ",.0f"),
+    "C3_MEASURE_VALUE": (lambda: _json(f"{R}_bench_measure_n1.json")["value"], ",.0f"),
     "SHARD4_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/4 rng_mode 0")[0], ",.0f"),
     "SHARD2_VALUE": (lambda: _shard(r"^stress 1920x1080x4096 shard 0/2 rng_mode 0")[0], ",.0f"),
     "C4SHARD_VALUE": (lambda: _shard(r"^cover-glass 3840x2160x1024 shard 0/8 rng_mode 0")[0], ",.0f"),

@@ -22,10 +22,10 @@ def test_bench_and_profiles_describe_the_same_sources():
     """The committed headline line, the PMC summaries bench.py copies its valu_issue from, and the library that produced the
     line name one source hash."""
     import json
-    b = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")))
     assert b["lib_build_id"] == b["source_sha16"] and b["lib_matches_sources"] is True
-    for name in ("r04_c3_pmc.json", "r04_c5_pmc.json"):
+    for name in ("r05_c3_pmc.json", "r05_c5_pmc.json"):
         assert json.load(open(os.path.join(ROOT, "profiles", name)))["source_sha16"] == b["source_sha16"], name
-    for name in ("r04_bench_c1_n1.json", "r04_bench_c2_n1.json", "r04_bench_c4_n1.json", "r04_bench_c5_n1.json"):
+    for name in ("r05_bench_c1_n1.json", "r05_bench_c2_n1.json", "r05_bench_c4_n1.json", "r05_bench_c5_n1.json"):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         assert d["source_sha16"] == b["source_sha16"] and d["cpu_baseline"]["value"] > 0, name
