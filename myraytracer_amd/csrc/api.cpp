@@ -1343,7 +1343,7 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
     // -- not this call's count alone, which dips whenever a convoy of frames has just ended (launched a little wider, the next
     // frame then holds more of the chip and the dips feed on themselves: C5's 1/8 share 3,066 -> 2,840 Msamples/s), and which is
     // 0, 1, 2, ... while a burst of calls fills an empty pipeline.  A new setting starts from "the caller keeps them all in
-    // flight"; a caller that waits for every frame is known for one after that many calls.
+    // flight".
     {
         const uint32_t window = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots);
         if (c->running_seen_n != window) {          // (a new setting, or the first call)
@@ -1351,6 +1351,11 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
             for (uint32_t i = 0; i < window; i++) c->running_seen[i] = window - 1u;
         }
         c->running_seen[c->frame_seq % window] = running;
+        // ... except that NOTHING running at three calls in a row is a caller that waits for every frame (a pipeline that is
+        // kept full never shows that): known at once, not after a window of up to sixteen slow frames
+        c->nothing_running_calls = running == 0u ? c->nothing_running_calls + 1u : 0u;
+        if (c->nothing_running_calls >= 3u)
+            for (uint32_t i = 0; i < window; i++) c->running_seen[i] = 0u;
         uint32_t most = 0;
         for (uint32_t i = 0; i < window; i++) most = std::max(most, c->running_seen[i]);
         *frames_running = most;

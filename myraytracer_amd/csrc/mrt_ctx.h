@@ -110,6 +110,7 @@ struct mrt_ctx {
     bool slots_probed = false;
     uint32_t last_launch_div = 1, last_frames_running = 0;   // mrt_get_schedule: what the most recent launch was issued with
     uint32_t running_seen[kMaxFrameSlots] = {}, running_seen_n = 0;    // frames seen queued or running at the last calls (schedule_frame)
+    uint32_t nothing_running_calls = 0;             // consecutive calls that found no earlier frame queued or running
     // settled settings by workload, so that a change of camera / samples per frame / scene and back does not start the trials
     // over (and a viewer that moves its camera every frame still reaches one)
     struct WidthMemo { uint32_t n_tiles, spp, large, counter, n_spheres, div, mult; };

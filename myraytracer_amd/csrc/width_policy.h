@@ -56,19 +56,21 @@ inline uint32_t width_frames_in_flight(uint32_t div, uint32_t mult, uint32_t max
 //    ray_depth wave-iterations in sequence -- not by throughput, and every iteration is shorter with fewer resident waves: a
 //    quarter of the waves, four frames side by side (the trials go on from there: 1080p at 1 spp ends at an eighth, sixteen
 //    in flight: 7,150 -> 9,810 Msamples/s).
-//  * Frames with tiles to spare (four per persistent wave and more): a half, and -- the rule for every narrow launch -- TWICE the
+//  * Frames with tiles to spare (three per persistent wave and more: six per wave of a half-width launch): a half, and -- the
+//    rule for every narrow launch -- TWICE the
 //    frames the chip holds.  Frames end out of order and a slot is reused only when its own frame has ended, so with exactly
 //    as many launches as fit, wave slots stand empty between a launch's end and the next launch on its slot; a queued launch
 //    takes every workgroup slot the moment it frees (profiles/r05_schedule_sweep.txt: C5 4,134 -> 4,245 Msamples/s, its 1/2,
 //    1/4, 1/8 shares 4,119 / 3,975 / 3,193 -> 4,223 / 4,101 / 3,814, C3 12,645 -> 12,851, C4's 1/8 share 12,157 -> 12,517, C2
-//    13,051 -> 13,496; every (div, 2) measured beats its (div, 1)).
+//    13,051 -> 13,496; every (div, 2) measured beats its (div, 1); C4's 1/8 share, 3.2 tiles per wave: (1, 1) 12,195, (2, 2)
+//    12,457, (4, 2) 12,185).
 inline uint32_t width_mult_for(uint32_t div, uint32_t max_slots) { return (div >= 2u && 2u * div <= max_slots) ? 2u : 1u; }
 inline void width_policy_start(WidthState& s, const WidthWorkload& w) {
     const uint32_t slots = width_max_u32(w.max_slots, 2u), narrowest = width_min_u32(kMaxWidthDiv, slots);
     const bool starved = !w.counter && w.spp >= 64u && (uint64_t)w.n_tiles < 2ull * w.n_waves && w.n_tiles > w.n_waves / narrowest;
     const bool short_chains = w.spp < 4u && (uint64_t)w.n_tiles * 4u >= 2ull * w.n_waves;
     s = WidthState();
-    s.div = starved ? narrowest : short_chains ? width_min_u32(4u, slots) : (!w.counter && w.n_tiles >= 4u * w.n_waves) ? 2u : 1u;
+    s.div = starved ? narrowest : short_chains ? width_min_u32(4u, slots) : (!w.counter && w.n_tiles >= 3u * w.n_waves) ? 2u : 1u;
     if (!short_chains) s.mult = width_mult_for(s.div, slots);
 }
 
