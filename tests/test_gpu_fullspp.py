@@ -173,8 +173,8 @@ def test_c5_counter_mode_at_4096_spp_whole_frame_and_eighth_shares(mrt):
 
 def test_c5_stream_mode_eighth_shares_with_eight_frames_in_flight(mrt):
     """The launch shape of `bench.py --config c5 --gpus 8` in the reference's RNG semantics: a 1/8 share of C5 is pixel-starved
-    (259,200 pixels for 262,144 resident lanes, one sequential 4,096-sample chain each), so mrt_redraw runs up to eight such
-    frames at a time, each on an eighth of the waves (api.cpp redraw_frames).  For the ranks that own the fixture rows 10 / 500
+    (259,200 pixels for 262,144 resident lanes, one sequential 4,096-sample chain each), so mrt_redraw runs up to sixteen such
+    frames at a time, each on an eighth of the waves (width_policy.h: eight fit, eight more wait in their queues).  For the ranks that own the fixture rows 10 / 500
     / 900: frame 0 of the share against the oracle's rows (and the pixel costs against their world_hit_calls); then three
     frames issued back to back -- in flight together -- against the same three frames rendered strictly one after the other:
     scheduling must not change a bit."""
