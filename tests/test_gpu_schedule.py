@@ -55,6 +55,36 @@ def test_forced_schedule_transitions_mid_accumulation_are_bit_identical(mrt, ora
     assert counters["world_hit_calls"] == cnt.world_hit_calls and counters["rng_draws"] == cnt.rng_draws
 
 
+def test_random_schedule_changes_every_few_frames_do_not_change_a_bit(mrt, oracle):
+    """40 frames of a large-scene layout (boxes, work stacks) and 40 of a small one, the pinned schedule drawn anew every one to
+    three frames from every valid (div, mult), with a read-back here and there (a caller that suddenly waits): each change
+    drains the pipeline and re-allocates slots under the accumulation.  Against the oracle's 40 frames, bit for bit."""
+    rng = np.random.default_rng(20251005)
+    valid = [(d, m) for d in range(1, 9) for m in range(1, 9) if max(2, d) * m <= 16]
+    for name, (spheres, cam), (w, h, spp, depth) in (("stress-36", mrt.scene_stress(3, 36), (96, 56, 3, 12)),
+                                                      ("cover", mrt.scene_cover(2, True), (120, 72, 2, 20))):
+        frames = 40
+        with mrt.State(mrt.Args(w, h, spp, depth, 1.0), seed=77) as st:
+            st.set_world(spheres); st.set_camera(cam)
+            f = 0
+            while f < frames:
+                div, mult = valid[int(rng.integers(0, len(valid)))]
+                st.set_schedule_hint(div, mult)
+                for _ in range(int(rng.integers(1, 4))):
+                    if f == frames:
+                        break
+                    st.redraw()
+                    f += 1
+                    if rng.random() < 0.15:
+                        st.read_framebuffer()
+            got = st.read_framebuffer()
+            c = st.read_counters()
+        cnt = oracle.Counters()
+        ref = oracle_render(oracle, spheres, cam, w, h, spp, depth, 77, frames, 1.0, counters=cnt)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), name + ": " + mismatch_report(got, ref)
+        assert c["world_hit_calls"] == cnt.world_hit_calls and c["rng_draws"] == cnt.rng_draws, name
+
+
 def test_schedule_hint_is_validated_and_released(mrt):
     spheres, cam = mrt.scene_cover(1, True)
     with mrt.State(mrt.Args(64, 40, 4, 8, 1.0), seed=3) as st:
