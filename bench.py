@@ -217,14 +217,18 @@ def load_schedules():
         return {}
 
 
-def settle(st, step, fence, all_settled, max_frames, max_seconds, done=0):
+def settle(st, step, fence, agree, max_frames, max_seconds, done=0):
     """Run untimed steps until the launch schedule is final for this workload (every rank's) AND three generations of frames
     (3 x the frames in flight, `done` of them rendered already) have gone through the pipeline at it -- the first generation
-    starts on an empty chip, the second still inherits its convoys -- or the cap.  Returns the steps run."""
+    starts on an empty chip, the second still inherits its convoys -- or the cap.  `agree(ready, capped)` -> (every rank is ready,
+    some rank has hit its cap): with N > 1 a step holds a collective, so all ranks must leave this loop in the same iteration
+    (their clocks differ).  Returns the steps run."""
     n, t0 = 0, time.perf_counter()
-    while n < max_frames and time.perf_counter() - t0 < max_seconds:
+    while True:
         sch = st.get_schedule()
-        if all_settled(sch["settled"] and done + n >= 3 * sch["frames_in_flight"]):
+        ready, capped = agree(bool(sch["settled"]) and done + n >= 3 * sch["frames_in_flight"],
+                              n >= max_frames or time.perf_counter() - t0 >= max_seconds)
+        if ready or capped:
             break
         step()
         n += 1
@@ -262,7 +266,7 @@ def other_config_rates(M, schedules, budget_s):
                 if pin:
                     s2.set_schedule_hint(int(pin["div"]), int(pin["mult"]))
                 else:
-                    settle_frames = settle(s2, s2.redraw, s2.sync, bool, 400, 12.0)
+                    settle_frames = settle(s2, s2.redraw, s2.sync, lambda ready, capped: (ready, capped), 400, 12.0)
                 for _ in range(warm if pin else 0):     # fill the pipeline
                     s2.redraw()
                 s2.sync()
@@ -468,15 +472,15 @@ def main():
     # frames (a trial = a sync of everything in flight and a different launch width), and a decision inside the timed steps would
     # make the line depend on it.  Untimed steps beyond --warmup, until every rank's schedule is final (or a cap), reported as
     # `settle_frames`; a pinned schedule is final from the first frame.  With N > 1 all ranks then take rank 0's.
-    def all_settled(mine):
+    def agree(ready, capped):
         if not use_dist:
-            return bool(mine)
-        flag = torch.tensor([1.0 if mine else 0.0], dtype=torch.float64, device=gather_device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(flag.item() > 0.5)
+            return ready, capped
+        flags = torch.tensor([1.0 if ready else 0.0, 0.0 if capped else 1.0], dtype=torch.float64, device=gather_device)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        return bool(flags[0].item() > 0.5), bool(flags[1].item() < 0.5)
     settle_frames = 0
     if a.frames_per_step == 1 and a.steps > 0:
-        settle_frames = settle(st, step, fence, all_settled, 600, 30.0, done=a.warmup)
+        settle_frames = settle(st, step, fence, agree, 600, 30.0, done=a.warmup)
         if use_dist:
             before = st.get_schedule()
             shared = mdist.share_schedule(st, 0)

@@ -225,7 +225,8 @@ int mrt_redraw(mrt_ctx* ctx);
  * side by side in this process (hardware queues: GPU_MAX_HW_QUEUES; 0 = not measured yet).
  * mrt_set_schedule_hint pins (div, mult) -- e.g. what an earlier run of the same workload settled at, or rank 0's setting on
  * every rank of a multi-GPU run -- so that no trial runs and two runs schedule alike; (0, 0) returns to the measured
- * setting.  div 1..8, mult 1..8, max(2, div) x mult <= 16.  Takes effect at the next redraw (a change waits for the frames
+ * setting.  div 1..8, mult 1..8, max(2, div) x mult <= 16; the frames in flight are held to out[5] where that has been measured
+ * (a process with too few hardware queues).  Takes effect at the next redraw (a change waits for the frames
  * under way); the images are the same whatever the schedule. */
 int mrt_get_schedule(mrt_ctx* ctx, uint32_t out[6]);
 int mrt_set_schedule_hint(mrt_ctx* ctx, uint32_t div, uint32_t mult);

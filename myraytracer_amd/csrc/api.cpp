@@ -1285,7 +1285,7 @@ static mrt::WidthWorkload width_workload(const mrt_ctx* c, bool counter) {
 // its convoys: judged on those, C3 read 4 % faster at a quarter width, where it renders 2 % less)
 static void width_restart_measurement(mrt_ctx* c) {
     c->width_timing = false;
-    c->width_valid_from = c->frame_seq + 2u * mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots);
+    c->width_valid_from = c->frame_seq + 2u * mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots);
     c->stat_base.valid = c->stat_last.valid = false;
 }
 
@@ -1345,7 +1345,7 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
     // 0, 1, 2, ... while a burst of calls fills an empty pipeline.  A new setting starts from "the caller keeps them all in
     // flight".
     {
-        const uint32_t window = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots);
+        const uint32_t window = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots);
         if (c->running_seen_n != window) {          // (a new setting, or the first call)
             c->running_seen_n = window;
             for (uint32_t i = 0; i < window; i++) c->running_seen[i] = window - 1u;
@@ -1417,6 +1417,8 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
     // more than two frames in flight only where they really run side by side (measured once, when a setting first asks for them)
     if (mrt::width_frames_in_flight(c->width.div, c->width.mult, mrt_ctx::kMaxFrameSlots) > 2u && !c->slots_probed) {
         MRT_TRY(probe_max_slots(c));
+        // (a pinned setting keeps its width and is held to the frames that run side by side all the same: sixteen frames on
+        // fewer queues take turns -- C5's 1/8 share 2,790 Msamples/s, less than eight in flight give)
         if (c->max_slots < mrt_ctx::kMaxFrameSlots && c->hint_div == 0) {       // start over within what the process can do
             w.max_slots = c->max_slots;
             mrt::width_policy_start(c->width, w);
@@ -1424,7 +1426,7 @@ static int schedule_frame(mrt_ctx* c, bool counter, uint32_t* want, uint32_t* fr
         }
         c->running_seen_n = 0;
     }
-    *want = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots);
+    *want = mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots);
     return MRT_OK;
 }
 
@@ -1899,7 +1901,7 @@ int mrt_set_wait_timeout(mrt_ctx* c, double seconds) {
 int mrt_get_schedule(mrt_ctx* c, uint32_t out[6]) {
     if (!c || !out) return MRT_ERR_INVALID_ARG;
     out[0] = c->width.div; out[1] = c->width.mult; out[2] = c->width.settled;
-    out[3] = c->width.div ? mrt::width_frames_in_flight(c->width.div, c->width.mult, c->hint_div ? mrt_ctx::kMaxFrameSlots : c->max_slots) : c->frame_slots;
+    out[3] = c->width.div ? mrt::width_frames_in_flight(c->width.div, c->width.mult, c->max_slots) : c->frame_slots;
     out[4] = c->last_launch_div;
     out[5] = c->slots_probed ? c->max_slots : 0u;        // 0 = not measured yet (no setting has asked for more than two frames)
     return MRT_OK;

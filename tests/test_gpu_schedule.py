@@ -34,10 +34,12 @@ def test_forced_schedule_transitions_mid_accumulation_are_bit_identical(mrt, ora
             st.redraw()
             sch = st.get_schedule()
             assert (sch["div"], sch["mult"], sch["settled"]) == (div, mult, True)
+            # (held to the frames this process can run side by side, where the library has measured that)
+            assert sch["frames_in_flight"] == min(max(2, div) * mult, sch["max_concurrent_frames"] or 16)
             seen.append(sch["frames_in_flight"])
         got = st.read_framebuffer()
         counters = st.read_counters()
-    assert seen == [max(2, d) * m for d, m in plan], seen
+    assert max(seen) >= 8 and seen[0] == 2, seen
     with mrt.State(args, seed=11) as st:                 # one frame after the other, nothing in flight
         st.set_world(spheres); st.set_camera(cam)
         st.debug_set_frames_in_flight(1)
@@ -94,10 +96,12 @@ def test_schedule_hint_is_validated_and_released(mrt):
                 st.set_schedule_hint(*bad)
         st.set_schedule_hint(4, 2)
         st.redraw()
-        assert st.get_schedule()["frames_in_flight"] == 8
+        sch = st.get_schedule()
+        assert sch["frames_in_flight"] == min(8, sch["max_concurrent_frames"] or 16)
         st.set_schedule_hint(8, 2)                       # twice the launches the chip holds
         st.redraw()
-        assert st.get_schedule()["frames_in_flight"] == 16
+        sch = st.get_schedule()
+        assert sch["frames_in_flight"] == min(16, sch["max_concurrent_frames"] or 16)
         st.set_schedule_hint(0, 0)                       # back to the measured setting
         st.redraw()
         sch = st.get_schedule()
