@@ -1,5 +1,7 @@
 #!/bin/bash
-# Dev helper (GPU box): the 24-byte boxes -- GPU tests, then large-scene rates (the same commands before / after)
+# Dev helper (GPU box): A/B of a large-scene kernel change -- the GPU tests, then the large-scene rates of the product library and of a
+# second build of the library under myraytracer_amd/lib/ (the previous commit's: git worktree add /tmp/wt HEAD && make there), same commands.
+# Round 5: 32- vs 24-byte boxes (profiles/r05_boxes_24_vs_32_bytes.txt), 24-byte boxes vs 80-byte sibling blocks (r05_boxes_20_vs_24_bytes.txt).
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r05l; mkdir -p $O
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/tests.txt 2>&1; echo "tests rc=$?" | tee -a $O/tests.txt
