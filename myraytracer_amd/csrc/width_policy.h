@@ -70,7 +70,10 @@ inline void width_policy_start(WidthState& s, const WidthWorkload& w) {
     const bool starved = !w.counter && w.spp >= 64u && (uint64_t)w.n_tiles < 2ull * w.n_waves && w.n_tiles > w.n_waves / narrowest;
     const bool short_chains = w.spp < 4u && (uint64_t)w.n_tiles * 4u >= 2ull * w.n_waves;
     s = WidthState();
-    s.div = starved ? narrowest : short_chains ? width_min_u32(4u, slots) : (!w.counter && w.n_tiles >= 3u * w.n_waves) ? 2u : 1u;
+    // (... a quarter for large scenes, whose pixels' chains differ 10 x: C5's 1/2 share 4,121 Msamples/s at a half x 2, 4,447 at a
+    // quarter x 2; C5 and scenes of 1,297 to 4,901 spheres the same within 1 % either way: profiles/r05_schedule_sweep.txt)
+    const uint32_t spare = (w.n_members > 1024u && slots >= 8u) ? 4u : 2u;
+    s.div = starved ? narrowest : short_chains ? width_min_u32(4u, slots) : (!w.counter && w.n_tiles >= 3u * w.n_waves) ? spare : 1u;
     if (!short_chains) s.mult = width_mult_for(s.div, slots);
 }
 

@@ -30,7 +30,8 @@ def step(mrt, w, s, util, rate):
 def test_what_is_known_up_front(mrt):
     assert start(mrt, C3)[:2] == [2, 2]                  # tiles to spare: a half, twice the launches the chip holds
     assert start(mrt, (480 * 34, 5120, 16, 1024, 488, 0))[:2] == [2, 2]     # C4's 1/8 share: 3.2 tiles per wave
-    assert start(mrt, C5)[:2] == [2, 2]
+    assert start(mrt, C5)[:2] == [4, 2]                  # ... a quarter for large scenes (their pixels' chains differ 10 x)
+    assert start(mrt, slots(C5, 4))[:2] == [2, 2]
     assert start(mrt, C2)[:2] == [1, 1]
     assert start(mrt, C1)[:2] == [1, 1]
     assert start(mrt, C5_EIGHTH)[:2] == [8, 2]           # pixel-starved share of long chains: an eighth, sixteen in flight
