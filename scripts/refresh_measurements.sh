@@ -12,9 +12,9 @@ PART=${1:-a}
 if [ "$PART" = "a" ]; then
 python -m pytest tests -m gpu -q > $O/gputests.log 2>&1 || true; tail -2 $O/gputests.log
 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err
-python bench.py --config c4 --steps 8 --warmup 2 > $O/bench_c4.json 2>/dev/null
-python bench.py --config c5 --steps 8 --warmup 4 > $O/bench_c5.json 2>/dev/null
-python bench.py --config c5 --rng counter --no-cpu-baseline --steps 6 --warmup 2 > $O/bench_c5_counter.json 2>/dev/null
+python bench.py --config c4 --steps 16 --warmup 2 > $O/bench_c4.json 2>/dev/null
+python bench.py --config c5 --steps 16 --warmup 4 > $O/bench_c5.json 2>/dev/null
+python bench.py --config c5 --rng counter --no-cpu-baseline --steps 12 --warmup 2 > $O/bench_c5_counter.json 2>/dev/null
 python bench.py --config c1 --steps 3000 --warmup 5 > $O/bench_c1.json 2>/dev/null
 python bench.py --config c1 --no-cpu-baseline --frames-per-step 32 --steps 20 --warmup 2 > $O/bench_c1_x32.json 2>/dev/null
 python bench.py --config c2 --steps 150 --warmup 5 > $O/bench_c2.json 2>/dev/null
