@@ -1,4 +1,6 @@
 #!/bin/bash
+# Dev helper (GPU box): large scenes of several sizes and C5's 1/2 share under a half / a quarter / an eighth x 2 -> gpurun_out/r05n/sweep3.txt
+# (appended to profiles/r05_schedule_sweep.txt: what the starting rule for large scenes rests on)
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 O=gpurun_out/r05n; mkdir -p $O
 run() { MRT_SHARD=$1 MRT_HINT=$2 MRT_WARMUP=$3 timeout -k 10 300 python scripts/wall_rate.py $5 $6 $7 $8 $4 2>&1 | grep -v amdgpu.ids | sed -e 's/HIER=None BOXES=None RNG=None//' -e "s/^/shard $1 hint $2: /" | cut -c1-112; }
