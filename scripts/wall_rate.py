@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev helper (GPU box): pipelined wall-clock Msamples/s of one workload under the tuning switches.
-   [MRT_HIER=levels,top] [MRT_BOXES=0|1] [MRT_RNG=1] [MRT_HINT=div,mult] [MRT_READ_EVERY=1] [MRT_SHARD=rank,world]
+   [MRT_HIER=levels,top] [MRT_BOXES=0|1] [MRT_RNG=1] [MRT_HINT=div,mult] [MRT_READ_EVERY=1] [MRT_SHARD=rank,world] [MRT_STEADY=1]
    python scripts/wall_rate.py scene w h spp steps"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,8 +30,10 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=shard) as st:
     st.sync()
     c0 = st.read_counters()
     t0 = time.perf_counter()
+    stamps = []
     for _ in range(steps):
         st.redraw()
+        stamps.append(time.perf_counter())         # (a call returns when the oldest frame in flight has ended: the back-pressure)
         if read_every: st.read_framebuffer()
     st.sync()
     dt = time.perf_counter() - t0
@@ -40,3 +42,11 @@ with M.State(M.Args(w, h, spp, 50, 1.0), seed=1, shard=shard) as st:
     print(f"{scene} {w}x{h}x{spp} HIER={os.environ.get('MRT_HIER')} BOXES={os.environ.get('MRT_BOXES')} RNG={os.environ.get('MRT_RNG')}: "
           f"{w * h * spp * steps / dt * 1e-6 / (shard[1] if shard else 1):.0f} Msamples/s, {dt / steps * 1e3:.1f} ms/step, lane util {util:.3f}, top {c1['sweep_records']}, "
           f"{'read back every frame, ' if read_every else ''}schedule {st.get_schedule()}", flush=True)
+    if os.environ.get("MRT_STEADY") and not read_every:
+        # the pipelined rate WITHOUT the run's fill and drain: calls are paced by completions, so between the return of call a and
+        # the return of the last call exactly (steps - 1 - a) frames have ended, with the pipeline full at both instants
+        f = st.get_schedule()["frames_in_flight"]
+        a = min(2 * f, steps // 3)
+        n_done, span = steps - 1 - a, stamps[-1] - stamps[a]
+        print(f"    steady state (frames ending between call {a} and call {steps - 1}, {f} in flight throughout): "
+              f"{w * h * spp * n_done / span * 1e-6 / (shard[1] if shard else 1):.0f} Msamples/s per GPU over {span:.1f} s", flush=True)
