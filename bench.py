@@ -246,7 +246,7 @@ def other_config_rates(M, schedules, budget_s):
         ("c4", "cover-glass", 3840, 2160, 1024, 50, None, 4, 8, "c4_n1"),
         ("c5", "stress", 1920, 1080, 4096, 50, None, 4, 8, "c5_n1"),
         # (sixteen frames in flight: the pipeline's start -- sixteen launches at once -- takes two rounds of frames to even out)
-        ("c5_share_1_of_8", "stress", 1920, 1080, 4096, 50, (0, 8), 32, 32, "c5_n8"),
+        ("c5_share_1_of_8", "stress", 1920, 1080, 4096, 50, (0, 8), 32, 96, "c5_n8"),
     ]
     out, t_begin = {}, time.perf_counter()
     for name, scene, w, h, spp, depth, shard, warm, steps, key in legs:
@@ -708,6 +708,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spheres, cam, width, height, a.depth, seed)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not use_dist and headline and a.config == "c3" and not a.no_other_configs and a.steps > 0:
+            st.close()          # (everything of the headline's context has been read; its streams need not sit beside the side legs')
             out["other_configs"] = other_config_rates(M, schedules if a.schedule == "hint" else {}, 90.0)
 
     # ---- N > 1: the C ABI's own gathers on the same workload, after everything that is timed for `value`.  Non-fatal by
